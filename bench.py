@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- DT + NN-fill frames/s at 352x1216 on N MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (dtfill_batch through the C ABI) over one batch of
+B=32 synthetic KITTI-shaped frames per GPU (BASELINE.json configs[1]; 5 % valid pixels, depths on
+KITTI's k/256 grid), inputs resident in HBM before the timed region, all three outputs (filled
+depth, distance map, NN index map) written to HBM.  N>1: one process per GPU, each with its own 32
+frames (frames are independent: no data-path collective; "scaling": "weak"), timing bracketed by a
+barrier + synchronize, MAX over ranks.
+
+Prints ONE JSON line on rank 0, with
+  roofline      the slowest kernel of the pass, timed with HIP events on the launch stream:
+                achieved = 16 B/pixel x pixels per launch / its mean duration, vs 8 TB/s HBM peak
+  cpu_baseline  the CPU restatement of the reference path (oracle/, kind "port") timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PKG = "distancetransform-depthcompletion_amd"
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_PIXEL = 16   # read f32 depth, write f32 depth + f32 distance + i32 index
+
+
+def cpu_baseline(x, budget_s=12.0):
+    """Oracle (CPU port of the reference path) over frames of x, one frame per task on a thread
+    pool over all host cores (ctypes releases the GIL; OpenCV's labels transform is serial per
+    frame, so frames are the unit of parallelism)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+
+    O.lib()
+    cores = os.cpu_count() or 1
+    B = x.shape[0]
+    t0 = time.perf_counter()
+    O.fill_batch(x[:1])
+    per_frame = time.perf_counter() - t0
+    n = int(max(cores, min(50 * cores, budget_s * cores / max(per_frame, 1e-4))))
+    frames = [x[i % B : i % B + 1] for i in range(n)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda f: O.fill_batch(f), frames))
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": "%d frames 352x1216 (the bench batch, cycled), C restatement of cv2 L1/5x5 labels "
+                  "transform + tools.py glue, one frame per thread, %d threads, %.1f s" % (n, cores, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--workload", default="kitti_b32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    op = pkg.device.DtFill(device=dev)
+
+    cfg = synth.CONFIGS[args.workload]
+    xh = synth.make(args.workload, B=args.batch, seed=cfg["kwargs"]["seed"] + rank)
+    B, H, W = xh.shape
+    x = torch.from_numpy(xh).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        op.run(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        op.run(x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations (HIP events on the launch stream), mean over a few instrumented passes
+    reps = 10
+    acc = {}
+    for _ in range(reps):
+        op.run(x, timed=True)
+        for k, v in op.last_kernel_ms.items():
+            acc[k] = acc.get(k, 0.0) + v / reps
+    status_bad = int((op.run(x)["status"] != 0).sum().item())
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        frames = world * B * args.steps
+        ms_per_step = 1e3 * elapsed / args.steps
+        dom = max(acc, key=acc.get)
+        algo_bytes = BYTES_PER_PIXEL * B * H * W
+        achieved = algo_bytes / (acc[dom] * 1e-3) / 1e9
+        line = {
+            "metric": "DT+NN-fill frames/sec at 352x1216; achieved HBM GB/s vs peak",
+            "value": round(frames / elapsed, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32/u16 distances+indices, f32 depth",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: B=%d frames/GPU of %dx%d, %s" % (args.workload, B, H, W, json.dumps(cfg["kwargs"])),
+                "metric_mode": "l1_cv", "outputs": "depth+dt+index", "frames_per_gpu": B,
+                "parallelism": "frame-sharded x%d, no collective" % world,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
+                "pass_achieved_GBs": round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                "pass_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            },
+            "frames_with_index_error": status_bad,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(xh)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

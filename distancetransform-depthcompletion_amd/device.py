@@ -1,0 +1,130 @@
+"""Device-side plumbing: torch owns the HBM buffers and the stream, libdtfill.so does the work.
+
+`DtFill` is the batched operator behind the reference-named functions in tools.py.  It holds one
+workspace + output set per (B, H, W) so that repeated calls (the reference calls the op once per
+frame in a loop, demo.py:268-290 / eval_NYU.py:138-195) allocate nothing.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+WANT_ALL = ("depth", "dt", "index")
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "dtfill needs a HIP device (torch.cuda.is_available() is False); the operator has "
+            "no CPU fallback -- the CPU restatement under oracle/ is test infrastructure only"
+        )
+
+
+class DtFill:
+    """Batched DT + nearest-valid-depth fill on one GPU.
+
+    Parameters mirror the literals of the reference: src_thr is the 0.1 of tools.py:8 (0.001 in
+    eval_NYU.py:115), val_thr the 0.1 of tools.py:22; metric "l1_cv" is the reference's
+    cv2.DIST_L1 / mask 5 / DIST_LABEL_PIXEL transform.
+    """
+
+    def __init__(self, device=None, metric="l1_cv"):
+        _require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if metric not in _lib.METRICS:
+            raise ValueError("metric must be one of %s" % sorted(_lib.METRICS))
+        self.metric = _lib.METRICS[metric]
+        self._shape = None
+        self._ws = None
+        self._out = None
+
+    # -- buffers -------------------------------------------------------------------------------
+    def _ensure(self, B, H, W):
+        if self._shape == (B, H, W):
+            return
+        nbytes = self.lib.dtfill_workspace_bytes(B, H, W, self.metric)
+        if nbytes == 0:
+            _lib.check(-2)
+        self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        self._ws_off = (-self._ws.data_ptr()) % 256
+        self._ws_bytes = nbytes
+        self._out = {
+            "depth": torch.empty((B, H, W), dtype=torch.float32, device=self.device),
+            "dt": torch.empty((B, H, W), dtype=torch.float32, device=self.device),
+            "index": torch.empty((B, H, W), dtype=torch.int32, device=self.device),
+            "status": torch.empty((B,), dtype=torch.int32, device=self.device),
+        }
+        self._shape = (B, H, W)
+
+    def workspace_bytes(self, B, H, W):
+        return int(self.lib.dtfill_workspace_bytes(B, H, W, self.metric))
+
+    # -- the op --------------------------------------------------------------------------------
+    def run(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL, timed=False):
+        """x: float32 CUDA tensor [B,H,W] (contiguous).  Returns a dict of device tensors
+        (views of buffers owned by this object, overwritten by the next call) for the names in
+        `want`, plus "status" (int32 [B]).  Asynchronous on the current stream unless timed."""
+        if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 3 or not x.is_contiguous():
+            raise ValueError("x must be a contiguous float32 CUDA tensor [B,H,W]")
+        B, H, W = x.shape
+        with torch.cuda.device(x.device):
+            if x.device != self.device:
+                raise ValueError("x lives on %s, operator on %s" % (x.device, self.device))
+            self._ensure(B, H, W)
+            o = self._out
+            ptr = lambda name: o[name].data_ptr() if name in want else None
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            args = [
+                x.data_ptr(), B, H, W, float(src_thr), float(val_thr), self.metric,
+                ptr("depth"), ptr("dt"), ptr("index"), o["status"].data_ptr(),
+                self._ws.data_ptr() + self._ws_off, self._ws_bytes, stream,
+            ]
+            if timed:
+                nk = self.lib.dtfill_num_kernels(self.metric)
+                ms = (ctypes.c_float * nk)()
+                _lib.check(self.lib.dtfill_batch_timed(*args, ctypes.cast(ms, ctypes.c_void_p)))
+                names = [self.lib.dtfill_kernel_name(self.metric, k).decode() for k in range(nk)]
+                self.last_kernel_ms = dict(zip(names, [float(v) for v in ms]))
+            else:
+                _lib.check(self.lib.dtfill_batch(*args))
+        res = {k: o[k] for k in want}
+        res["status"] = o["status"]
+        return res
+
+    def run_numpy(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL):
+        """numpy in / numpy out: H2D, run, D2H.  x: float32 [B,H,W].  Raises IndexError exactly
+        where numpy would in depth_list[label_list-1] (tools.py:26) when depth is wanted."""
+        xh = np.ascontiguousarray(x, dtype=np.float32)
+        if xh.ndim != 3:
+            raise ValueError("x must be [B,H,W]")
+        xd = torch.from_numpy(xh).to(self.device, non_blocking=False)
+        res = self.run(xd, src_thr, val_thr, want)
+        out = {k: v.cpu().numpy() for k, v in res.items()}
+        if "depth" in want:
+            bad = np.nonzero(out["status"] == _lib.FRAME_INDEX_ERROR)[0]
+            if bad.size:
+                raise IndexError(
+                    "frame %d: index out of bounds in depth_list[label_list-1] "
+                    "(value list shorter than a label, or empty with label 0)" % int(bad[0])
+                )
+        return out
+
+
+_default_ops = {}
+
+
+def default_op(metric="l1_cv"):
+    """Process-wide operator on the current CUDA device (what the reference-named functions use)."""
+    _require_gpu()
+    key = (torch.cuda.current_device(), metric)
+    if key not in _default_ops:
+        _default_ops[key] = DtFill(metric=metric)
+    return _default_ops[key]
+
+
+def fill(x, src_thr=0.1, val_thr=0.1, metric="l1_cv", want=WANT_ALL):
+    """Batched numpy API: x [B,H,W] float32 -> dict(depth, dt, index, status)."""
+    return default_op(metric).run_numpy(x, src_thr, val_thr, want)

@@ -1,0 +1,99 @@
+/*
+ * dtfill.h -- C ABI of libdtfill.so: the MI355X (gfx950) distance-transform + nearest-valid-depth
+ * fill operator.  Plain pointers and sizes only; no torch / HIP types in the signatures
+ * (`stream` is a hipStream_t passed as void*, NULL = the default stream).
+ *
+ * What each entry point replaces in the reference (placeforyiming/DistanceTransform-DepthCompletion):
+ *
+ *   dtfill_batch()            the per-frame body of DT_complete_batch(), solution_DeepNet/tools.py:13-35
+ *                             (live copy demo.py:84-106), and Distance_Transform(),
+ *                             solution_DeepNet/eval_NYU.py:120-133, for B frames at once:
+ *                               nearest_point()                      tools.py:7-10 / eval_NYU.py:114-117
+ *                                 value_mask = uint8((1.0 - x) > src_thr)
+ *                                 cv2.distanceTransformWithLabels(value_mask, DIST_L1, 5, DIST_LABEL_PIXEL)
+ *                               with_value = x > val_thr ; depth_list = x[with_value]   tools.py:22,24
+ *                               out = depth_list[lbl - 1]                               tools.py:26
+ *                             out_dt / out_index are the (dt, lbl) pair nearest_point() returns.
+ *   dtfill_workspace_bytes()  the temporaries numpy/cv2 allocate implicitly (cv2's (H+4)x(W+4) int32
+ *                             `temp`, the masks, depth_list); here the caller owns them.
+ *   dtfill_strerror()         the numpy / cv2 exceptions the reference surfaces (tools.py:26 IndexError).
+ *
+ * All pointers are DEVICE pointers unless stated otherwise.  Frames are float32, C-contiguous
+ * [B, H, W] (the shim slices channel 0 of the reference's [B,H,W,1] layout).  The library keeps
+ * no global state, allocates nothing, and every call is ordered on `stream` only: it is safe to
+ * call from several host threads on different streams / devices with different workspaces.
+ */
+#ifndef DTFILL_H
+#define DTFILL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTFILL_ABI_VERSION 1
+
+/* metric */
+#define DTFILL_METRIC_L1_CV 0 /* reference parity: OpenCV L1 5x5 chamfer + its label tie-break order */
+#define DTFILL_METRIC_L2    1 /* exact Euclidean transform, tie-break = smallest raster index */
+
+/* return codes */
+#define DTFILL_OK               0
+#define DTFILL_ERR_NULL        -1 /* x, workspace or every output is NULL */
+#define DTFILL_ERR_SHAPE       -2 /* B,H,W < 1, or H+W-2 >= 8192 (cv2's Q16 INIT_DIST0 range) */
+#define DTFILL_ERR_WORKSPACE   -3 /* ws_bytes < dtfill_workspace_bytes() or workspace not 256-B aligned */
+#define DTFILL_ERR_METRIC      -4 /* unknown metric */
+#define DTFILL_ERR_LAUNCH      -5 /* a HIP launch failed (hipGetLastError) */
+#define DTFILL_ERR_NO_DEVICE   -6 /* no usable HIP device */
+
+/* per-frame status written to frame_status[b] (device int32) */
+#define DTFILL_FRAME_OK          0
+#define DTFILL_FRAME_INDEX_ERROR 1 /* numpy would raise IndexError in depth_list[lbl-1] (tools.py:26):
+                                      a label addresses past the value list, or label 0 (no source in
+                                      the frame) with an empty value list.  out_depth of that frame is
+                                      then unspecified; out_dt / out_index are still exact. */
+
+int dtfill_abi_version(void);
+const char *dtfill_strerror(int code);
+
+/* Bytes of scratch dtfill_batch() needs for this shape (0 on a bad shape). 256-B aligned carve. */
+size_t dtfill_workspace_bytes(int B, int H, int W, int metric);
+
+/*
+ * One pass of the hot path over B frames.
+ *   x            float32 [B,H,W], never written.
+ *   src_thr      a pixel is a SOURCE iff NOT((1.0f - x) > src_thr) in float32   (tools.py:8: 0.1,
+ *                eval_NYU.py:115: 0.001).  NaN is therefore a source, as in numpy.
+ *   val_thr      a pixel enters the value list iff x > val_thr                  (tools.py:22: 0.1)
+ *   out_depth    float32 [B,H,W] filled depth  = depth_list[lbl-1]              (nullable)
+ *   out_dt       float32 [B,H,W] distance map  (l1_cv: integer-valued L1, 8192.0 in a frame with
+ *                no source; l2: sqrtf of the exact squared distance, +inf if no source) (nullable)
+ *   out_index    int32 [B,H,W]: l1_cv: cv2's label (1-based raster rank of the nearest source under
+ *                cv2's tie-break, 0 = no source); l2: the same 1-based rank under the canonical
+ *                tie-break                                                      (nullable)
+ *   frame_status int32 [B] (nullable): DTFILL_FRAME_*
+ *   workspace    ws_bytes >= dtfill_workspace_bytes(B,H,W,metric), 256-B aligned
+ * Returns DTFILL_OK or a negative DTFILL_ERR_*.  Asynchronous: outputs are valid after `stream`
+ * has been synchronised.
+ */
+int dtfill_batch(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
+                 float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
+                 void *workspace, size_t ws_bytes, void *stream);
+
+/*
+ * Same pass, instrumented for bench.py: records a HIP event on `stream` before and after every
+ * kernel, synchronises, and returns each kernel's duration in milliseconds in kernel_ms (HOST
+ * float[dtfill_num_kernels(metric)]).  Not for production use (it blocks).
+ */
+int dtfill_num_kernels(int metric);
+const char *dtfill_kernel_name(int metric, int k);
+int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
+                       float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
+                       void *workspace, size_t ws_bytes, void *stream, float *kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTFILL_H */

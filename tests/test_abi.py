@@ -1,0 +1,69 @@
+"""libdtfill.so builds for gfx950, loads without a GPU, and exports exactly the symbols
+include/dtfill.h declares.  No compute call is made here."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "dtfill.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dtfill_[a-z_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(pkg):
+    pkg.build()
+    L = pkg.load()
+    decl = _declared()
+    assert decl == sorted(pkg._lib.SYMBOLS)
+    for name in decl:
+        assert hasattr(L, name), name
+
+
+def test_host_side_entry_points(pkg):
+    L = pkg.load()
+    assert L.dtfill_abi_version() == 1
+    assert L.dtfill_strerror(0) == b"ok"
+    assert b"shape" in L.dtfill_strerror(-2)
+    # workspace sizing is pure host arithmetic
+    assert L.dtfill_workspace_bytes(32, 352, 1216, 0) > 32 * 352 * 1216 * 9
+    assert L.dtfill_workspace_bytes(0, 352, 1216, 0) == 0
+    assert L.dtfill_workspace_bytes(1, 5000, 5000, 0) == 0  # beyond cv2's Q16 distance range
+    assert L.dtfill_workspace_bytes(1, 8, 8, 99) == 0
+    nk = L.dtfill_num_kernels(0)
+    assert nk >= 1 and all(L.dtfill_kernel_name(0, k) for k in range(nk))
+
+
+def test_argument_errors_without_gpu(pkg):
+    """Argument validation happens before any HIP call, so it is testable on the CPU box."""
+    L = pkg.load()
+    assert L.dtfill_batch(None, 1, 8, 8, 0.1, 0.1, 0, None, None, None, None, None, 0, None) == -1
+    assert L.dtfill_batch(256, 1, 8, 8, 0.1, 0.1, 0, None, None, None, None, 256, 1 << 20, None) == -1  # no output
+    assert L.dtfill_batch(256, 0, 8, 8, 0.1, 0.1, 0, 256, None, None, None, 256, 1 << 20, None) == -2
+    assert L.dtfill_batch(256, 1, 8, 8, 0.1, 0.1, 7, 256, None, None, None, 256, 1 << 20, None) == -4
+    assert L.dtfill_batch(256, 1, 8, 8, 0.1, 0.1, 0, 256, None, None, None, 256, 16, None) == -3  # too small
+    assert L.dtfill_batch(256, 1, 8, 8, 0.1, 0.1, 0, 256, None, None, None, 260, 1 << 20, None) == -3  # unaligned
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing in the package may import or load it."""
+    pkgdir = os.path.join(ROOT, "distancetransform-depthcompletion_amd")
+    for dp, _, files in os.walk(pkgdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "liboracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.nearest_point(np.zeros((4, 4), np.float32))

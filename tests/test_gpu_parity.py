@@ -1,0 +1,189 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden vectors.  Bar: bit-exact distance map, label map and gathered depth (integer / index work;
+the float outputs are exact copies or integer-valued, so the float tolerance is 0)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from helpers import digest, load_cases
+
+pytestmark = pytest.mark.gpu
+CASES, DIGESTS = load_cases()
+
+
+def run(op, x, st=0.1, vt=0.1, want=("depth", "dt", "index")):
+    import torch
+
+    xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to("cuda:0")
+    res = op.run(xd, st, vt, want)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in res.items()}
+
+
+def assert_equal_to_oracle(oracle, op, x, st=0.1, vt=0.1):
+    depth, dt, lbl, status = oracle.fill_batch(x, st, vt)
+    got = run(op, x, st, vt)
+    assert np.array_equal(got["dt"], dt), "distance map differs"
+    assert np.array_equal(got["index"], lbl), "label map differs: %d px" % (got["index"] != lbl).sum()
+    assert np.array_equal(got["status"], status)
+    ok = status == 0
+    assert np.array_equal(got["depth"][ok], depth[ok], equal_nan=True), "filled depth differs"
+
+
+def test_native_library_loaded(gpu_op, pkg):
+    import torch
+
+    assert torch.cuda.get_device_name(0)
+    maps = open("/proc/self/maps").read()
+    assert "libdtfill.so" in maps, "the HIP extension is not the code that ran"
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_golden_cases(gpu_op, name):
+    c = CASES[name]
+    got = run(gpu_op, c["x"][None], float(c["thr"][0]), float(c["thr"][1]))
+    assert np.array_equal(got["dt"][0], c["dt"])
+    assert np.array_equal(got["index"][0], c["lbl"])
+    assert np.array_equal(got["status"], c["status"])
+    if c["status"][0] == 0:
+        assert np.array_equal(got["depth"][0], c["depth"], equal_nan=True)
+
+
+def test_golden_cases_as_one_batch_per_shape(gpu_op):
+    """Frames of equal shape stacked into one batch: exercises B > 1 and per-frame status."""
+    by_shape = {}
+    for name, c in CASES.items():
+        if tuple(c["thr"]) == (np.float32(0.1), np.float32(0.1)):
+            by_shape.setdefault(c["x"].shape, []).append(c)
+    for shape, cs in by_shape.items():
+        x = np.stack([c["x"] for c in cs])
+        got = run(gpu_op, x)
+        for b, c in enumerate(cs):
+            assert np.array_equal(got["dt"][b], c["dt"]) and np.array_equal(got["index"][b], c["lbl"])
+            assert got["status"][b] == c["status"][0]
+            if c["status"][0] == 0:
+                assert np.array_equal(got["depth"][b], c["depth"], equal_nan=True)
+
+
+@pytest.mark.parametrize("cfg", sorted(DIGESTS))
+def test_full_size_digests(gpu_op, pkg, cfg):
+    """BASELINE.json's shapes: outputs hashed against the oracle's committed sha256."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    d = DIGESTS[cfg]
+    x = synth.make(cfg, B=d["B"])
+    assert digest(x) == d["x"]
+    got = run(gpu_op, x)
+    assert digest(got["dt"]) == d["dt"]
+    assert digest(got["index"]) == d["lbl"]
+    assert digest(got["depth"]) == d["depth"]
+    assert got["status"].tolist() == d["status"]
+
+
+def test_seeded_random_vs_oracle(gpu_op, oracle):
+    rng = np.random.default_rng(2024)
+    for t in range(40):
+        B = int(rng.integers(1, 4))
+        H, W = int(rng.integers(1, 90)), int(rng.integers(1, 200))
+        p = rng.choice([0.003, 0.02, 0.05, 0.3, 0.8])
+        x = np.where(rng.random((B, H, W)) < p, rng.uniform(0.95, 80, (B, H, W)), 0).astype(np.float32)
+        if t % 5 == 0:
+            x[:, : H // 2] = 0
+        if t % 7 == 0:
+            x[:, :, W // 3 :] = 0
+        assert_equal_to_oracle(oracle, gpu_op, x)
+
+
+def test_thresholds_and_misalignment_vs_oracle(gpu_op, oracle):
+    """eval_NYU.py's (0.001, 0.1) threshold pair with depths from 0.7 m: source and value
+    enumerations differ, the value list must be materialised."""
+    rng = np.random.default_rng(99)
+    x = np.where(rng.random((3, 120, 160)) < 0.02, rng.uniform(0.7, 10, (3, 120, 160)), 0).astype(np.float32)
+    x[0, 0, :5] = [0.5, 0.95, 0.9991, 0.3, 0.999]
+    assert_equal_to_oracle(oracle, gpu_op, x, 0.001, 0.1)
+    assert_equal_to_oracle(oracle, gpu_op, x, 0.1, 0.1)
+    assert_equal_to_oracle(oracle, gpu_op, x, 0.1, 0.6)  # fewer values than sources -> IndexError frames
+
+
+def test_sparse_long_chains_vs_oracle(gpu_op, oracle, pkg):
+    """Few sources in a big frame: distances in the hundreds, long parent chains."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    for n in (1, 3, 20):
+        x = synth.nyu_pattern(2, n=n, seed=n)
+        assert_equal_to_oracle(oracle, gpu_op, x)
+    x = np.zeros((1, 300, 500), np.float32)
+    x[0, 299, 0] = 2.0
+    assert_equal_to_oracle(oracle, gpu_op, x)
+    x[0, 0, 499] = 3.0
+    assert_equal_to_oracle(oracle, gpu_op, x)
+
+
+def test_batch32_kitti_properties(gpu_op, oracle, pkg):
+    """BASELINE config 2 at full size (B=32): size-independent properties on every frame, and a
+    full oracle comparison on a few of them."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    x = synth.make("kitti_b32")
+    got = run(gpu_op, x)
+    B, H, W = x.shape
+    ii, jj = np.indices((H, W))
+    for b in range(B):
+        src = x[b] >= 0.9
+        pos = np.argwhere(src)
+        lbl = got["index"][b]
+        assert lbl.min() >= 1 and lbl.max() <= len(pos)
+        # every label is a true L1-nearest source and dt is that distance
+        l1 = np.abs(ii - pos[lbl - 1, 0]) + np.abs(jj - pos[lbl - 1, 1])
+        assert np.array_equal(l1.astype(np.float32), got["dt"][b])
+        # sources keep their own rank and depth; the fill is the labelled source's depth
+        assert np.array_equal(lbl[src], np.arange(1, len(pos) + 1))
+        assert np.array_equal(got["depth"][b], x[b][pos[lbl - 1, 0], pos[lbl - 1, 1]])
+    # idempotence: a filled frame has every pixel valid, so filling it again changes nothing
+    again = run(gpu_op, got["depth"][:2])
+    assert np.array_equal(again["depth"], got["depth"][:2]) and (again["dt"] == 0).all()
+    for b in (0, 13, 31):
+        depth, dt, lbl, status = oracle.fill_batch(x[b : b + 1])
+        assert np.array_equal(got["dt"][b], dt[0]) and np.array_equal(got["index"][b], lbl[0])
+        assert np.array_equal(got["depth"][b], depth[0])
+
+
+def test_optional_outputs_and_reuse(gpu_op, oracle):
+    rng = np.random.default_rng(5)
+    x = np.where(rng.random((2, 50, 70)) < 0.05, rng.uniform(1, 80, (2, 50, 70)), 0).astype(np.float32)
+    depth, dt, lbl, _ = oracle.fill_batch(x)
+    for want in (("depth",), ("dt",), ("index",), ("dt", "index")):
+        got = run(gpu_op, x, want=want)
+        if "depth" in want:
+            assert np.array_equal(got["depth"], depth)
+        if "dt" in want:
+            assert np.array_equal(got["dt"], dt)
+        if "index" in want:
+            assert np.array_equal(got["index"], lbl)
+
+
+def test_reference_named_functions(pkg, oracle):
+    """The drop-in layer: same names / shapes / dtypes / exceptions as tools.py and eval_NYU.py."""
+    c = CASES["rand_p0.05"]
+    dt, lbl = pkg.nearest_point(c["x"])
+    assert dt.dtype == np.float32 and lbl.dtype == np.int32
+    assert np.array_equal(dt, c["dt"]) and np.array_equal(lbl, c["lbl"])
+    batch = np.stack([c["x"], c["x"][::-1].copy()])[..., None]
+    out = pkg.DT_complete_batch(batch)
+    assert out.shape == batch.shape and out.dtype == np.float32
+    assert np.array_equal(out, oracle.DT_complete_batch(batch))
+    one = pkg.Distance_Transform(c["x"][None, :, :, None].astype(np.float64))
+    assert one.dtype == np.float64 and np.array_equal(one, oracle.Distance_Transform(c["x"].astype(np.float64)))
+    with pytest.raises(IndexError):
+        pkg.DT_complete_batch(np.zeros((1, 6, 9, 1), np.float32))
+    with pytest.raises(IndexError):  # eval_NYU.py:125's 0-d squeeze of a one-element value list
+        pkg.Distance_Transform(CASES["single0"]["x"], 0.1)
+    with pytest.raises(TypeError):
+        pkg.nearest_point(np.full((4, 4), 0.1, np.float64))
+
+
+def test_shape_errors(gpu_op, pkg):
+    import torch
+
+    with pytest.raises(pkg.DtfillError):
+        gpu_op.run(torch.zeros((1, 5000, 5000), device="cuda:0"))
+    with pytest.raises(ValueError):
+        gpu_op.run(torch.zeros((5, 5), device="cuda:0"))

@@ -1,0 +1,111 @@
+"""The CPU oracle against its committed golden vectors and against independent checkers.
+
+PARITY UNPINNED (see oracle/dtfill_oracle.c): there is no cv2 here and the reference holds no
+recorded outputs of this path, so the independent anchors are scipy's taxicab transform (equal
+distances), the brute-force nearest-source search (every label is a true nearest source), and an
+opportunistic comparison with a real cv2 on whatever machine has one."""
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import digest, load_cases
+
+CASES, DIGESTS = load_cases()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_golden_cases(oracle, name):
+    c = CASES[name]
+    st, vt = float(c["thr"][0]), float(c["thr"][1])
+    depth, dt, lbl, status = oracle.fill_batch(c["x"][None], st, vt)
+    assert np.array_equal(dt[0], c["dt"])
+    assert np.array_equal(lbl[0], c["lbl"])
+    assert np.array_equal(status, c["status"])
+    if status[0] == 0:
+        assert np.array_equal(depth[0], c["depth"], equal_nan=True)
+
+
+def test_hand_case_values(oracle):
+    """the 5x7 worked example, written out."""
+    c = CASES["hand5x7"]
+    want_dt = np.array([[3, 2, 3, 2, 1, 0, 1], [2, 1, 2, 3, 2, 1, 2], [1, 0, 1, 2, 2, 2, 3],
+                        [2, 1, 2, 2, 1, 2, 3], [3, 2, 2, 1, 0, 1, 2]], np.float32)
+    want_lbl = np.array([[2, 2, 2, 1, 1, 1, 1], [2, 2, 2, 1, 1, 1, 1], [2, 2, 2, 2, 3, 1, 1],
+                         [2, 2, 2, 3, 3, 3, 3], [2, 2, 3, 3, 3, 3, 3]], np.int32)
+    dt, lbl = oracle.nearest_point(c["x"])
+    assert np.array_equal(dt, want_dt) and np.array_equal(lbl, want_lbl)
+    assert np.array_equal(oracle.Distance_Transform(c["x"], 0.1), np.choose(want_lbl - 1, [10.0, 20.0, 30.0]))
+
+
+@pytest.mark.parametrize("cfg", sorted(DIGESTS))
+def test_full_size_digests(oracle, pkg, cfg):
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    d = DIGESTS[cfg]
+    x = synth.make(cfg, B=d["B"])
+    assert digest(x) == d["x"], "synthetic generator changed"
+    depth, dt, lbl, status = oracle.fill_batch(x)
+    assert digest(dt) == d["dt"] and digest(lbl) == d["lbl"] and digest(depth) == d["depth"]
+    assert status.tolist() == d["status"]
+
+
+def test_against_scipy_and_bruteforce(oracle):
+    ndimage = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(7)
+    for _ in range(60):
+        H, W = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+        src = rng.random((H, W)) < rng.choice([0.02, 0.1, 0.4])
+        if not src.any():
+            src[H // 2, W // 2] = True
+        mask = (~src).astype(np.uint8)
+        dist, lab = oracle.cv_distance_transform_with_labels(mask)
+        assert np.array_equal(dist, ndimage.distance_transform_cdt(mask, metric="taxicab").astype(np.float32))
+        bd, _ = oracle.brute_nearest(mask, 1)
+        assert np.array_equal(dist.astype(np.int32), bd)
+        pos = np.argwhere(src)
+        ii, jj = np.indices((H, W))
+        assert np.array_equal(np.abs(ii - pos[lab - 1, 0]) + np.abs(jj - pos[lab - 1, 1]), bd)
+
+
+def test_glue_semantics(oracle):
+    """The literal numpy glue (tools.py:13-35 / eval_NYU.py:120-133) and the all-C glue agree,
+    including numpy's negative-index wrap and IndexError."""
+    # label 0 with a non-empty value list -> last value
+    c = CASES["nosource_values"]
+    out = oracle.DT_complete_batch(c["x"][None, :, :, None])
+    assert (out == np.float32(0.7)).all() and out.shape == (1, 6, 9, 1) and out.dtype == np.float32
+    # label 0 with an empty value list -> IndexError
+    with pytest.raises(IndexError):
+        oracle.DT_complete_batch(CASES["nosource_novalue"]["x"][None, :, :, None])
+    assert CASES["nosource_novalue"]["status"][0] == 1
+    # misaligned enumeration really shifts the labels' depths
+    c = CASES["misaligned"]
+    src_depth = c["x"][np.unravel_index(np.flatnonzero(c["x"].ravel() >= 0.9)[c["lbl"] - 1], c["x"].shape)]
+    assert (src_depth != c["depth"]).mean() > 0.5
+    # eval_NYU.py:125 squeezes a one-element value list to 0-d and then fails to index it
+    with pytest.raises(IndexError):
+        oracle.Distance_Transform(CASES["single0"]["x"], 0.1)
+    assert oracle.DT_complete_batch(CASES["single0"]["x"][None, :, :, None]).min() == 7.5
+
+
+def test_l2_oracle_against_bruteforce(oracle):
+    rng = np.random.default_rng(11)
+    for _ in range(40):
+        H, W = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+        mask = (rng.random((H, W)) > rng.choice([0.03, 0.2])).astype(np.uint8)
+        d0, n0 = oracle.brute_nearest(mask, 2)
+        d1, n1 = oracle.edt_l2(mask)
+        assert np.array_equal(d0, d1) and np.array_equal(n0, n1)
+
+
+def test_real_cv2_if_present(oracle):
+    """Opportunistic pin: on a machine that has OpenCV, the restatement must equal it."""
+    cv2 = pytest.importorskip("cv2")
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        mask = (rng.random((37, 53)) > 0.07).astype(np.uint8)
+        dt, lbl = cv2.distanceTransformWithLabels(mask, cv2.DIST_L1, 5, labelType=cv2.DIST_LABEL_PIXEL)
+        d0, l0 = oracle.cv_distance_transform_with_labels(mask)
+        assert np.array_equal(dt, d0) and np.array_equal(lbl, l0)

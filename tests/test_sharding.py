@@ -1,0 +1,75 @@
+"""N>1 path on the CPU: two gloo ranks shard a batch, each fills its frames, the host gather
+reassembles them in order.  The per-rank compute is injected (the oracle stands in for the GPU
+here -- in tests only), so what is under test is shard_range + gather_frames + fill_sharded."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range(pkg):
+    for n in (0, 1, 7, 32, 33, 256):
+        for world in (1, 2, 3, 8):
+            spans = [pkg.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert pkg.shard_range(256, 3, 8) == (96, 128)
+    with pytest.raises(ValueError):
+        pkg.shard_range(8, 2, 2)
+
+
+def _worker(rank, world, port, n_frames, q):
+    sys.path.insert(0, ROOT)
+    import importlib
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("distancetransform-depthcompletion_amd")
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(0)  # same batch on every rank
+    x = np.where(rng.random((n_frames, 24, 40)) < 0.06, rng.uniform(1, 80, (n_frames, 24, 40)), 0).astype(np.float32)
+
+    def compute(xs, st, vt, want):
+        depth, dt, idx, _ = O.fill_batch(xs, st, vt)
+        return {"depth": depth, "dt": dt, "index": idx}
+
+    full = pkg.fill_sharded(x, compute=compute)  # all_gather form
+    root_only = pkg.fill_sharded(x, compute=compute, dst=0)
+    depth, dt, idx, _ = O.fill_batch(x)
+    ok = all(np.array_equal(full[k], v) for k, v in (("depth", depth), ("dt", dt), ("index", idx)))
+    if rank == 0:
+        ok = ok and np.array_equal(root_only["index"], idx)
+    else:
+        ok = ok and root_only["index"] is None
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [5, 8])
+def test_two_rank_gloo_gather(n_frames):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
