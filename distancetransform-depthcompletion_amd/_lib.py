@@ -16,7 +16,11 @@ METRIC_L2 = 1
 METRICS = {"l1_cv": METRIC_L1_CV, "l2": METRIC_L2}
 
 FRAME_OK = 0
-FRAME_INDEX_ERROR = 1
+FRAME_INDEX_ERROR = 1  # bit
+FRAME_GENERAL_PATH = 2  # bit, informational
+FLAG_GENERAL_ONLY = 1
+FLAG_FUSED_ONLY = 2
+PATHS = {"auto": 0, "general": FLAG_GENERAL_ONLY, "fused": FLAG_FUSED_ONLY}
 
 # every symbol include/dtfill.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = (
@@ -24,6 +28,7 @@ SYMBOLS = (
     "dtfill_strerror",
     "dtfill_workspace_bytes",
     "dtfill_batch",
+    "dtfill_batch_flags",
     "dtfill_num_kernels",
     "dtfill_kernel_name",
     "dtfill_batch_timed",
@@ -74,11 +79,13 @@ def load():
     L.dtfill_workspace_bytes.restype = sz
     L.dtfill_batch.argtypes = [vp, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, sz, vp]
     L.dtfill_batch.restype = ci
+    L.dtfill_batch_flags.argtypes = [vp, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, sz, vp, ctypes.c_uint]
+    L.dtfill_batch_flags.restype = ci
     L.dtfill_num_kernels.argtypes = [ci]
     L.dtfill_num_kernels.restype = ci
     L.dtfill_kernel_name.argtypes = [ci, ci]
     L.dtfill_kernel_name.restype = ctypes.c_char_p
-    L.dtfill_batch_timed.argtypes = [vp, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, sz, vp, vp]
+    L.dtfill_batch_timed.argtypes = [vp, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, sz, vp, ctypes.c_uint, vp]
     L.dtfill_batch_timed.restype = ci
     _lib = L
     return L

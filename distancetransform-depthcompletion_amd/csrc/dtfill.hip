@@ -26,20 +26,27 @@
 // so all pixels of all frames are processed in parallel; only the final chain walk is data dependent
 // (chain length <= d(q) hops).
 //
-// Kernels (general path, any input):
-//   k_colscan  column scans: gu, g=min(gu,gd) (uint16) + source / value bit words (ballots)
-//   k_skew     knight-line scan: dB (uint16)
-//   k_rank     per-frame exclusive popcount scan of the bit words (compaction ranks), frame facts,
-//              value list (only materialised for frames whose source and value masks differ)
-//   k_rowscan  row scans: d, dA -> dl = d | live<<15 (uint16)
-//   k_parent   5x5 rule -> one parent code byte per pixel
-//   k_resolve  chain walk -> label, depth gather, float distance; the three output stores
+// Locality: everything that decides label(q) lies inside the L1 ball of radius d(q) around q.  So a
+// tile plus a halo of FR pixels, held in LDS, gives the exact result for every tile pixel with
+// d <= FR, and detects (d > FR) the ones it cannot decide.
 //
-// No MFMA anywhere: this path is compare/min/index work bounded by HBM traffic.
+// Kernels of one pass:
+//   k_mask     source / value bit words (ballots) + per-row prefix popcounts       reads x once
+//   k_frame    per-frame row-count scan -> compaction ranks; frame facts; value list when the source
+//              and value masks of a frame differ (else depth_list[lbl-1] == x at the source pixel)
+//   k_fused    one workgroup per (tile + halo) window, all of it in LDS: column scans, row scans,
+//              knight-line scan, 5x5 parent rule, chain walk, rank lookup, depth gather, and the
+//              three output stores.  Flags the frame if any tile pixel has d > FR.
+//   general path (only frames flagged by k_fused; blocks of other frames exit at once):
+//   k_colscan, k_skew, k_rowscan, k_parent, k_resolve -- the same mathematics with full-frame scans
+//              through HBM, valid for any distance.
+//
+// No MFMA anywhere: this path is compare/min/index work (DESIGN.md "Roofline").
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include "../../include/dtfill.h"
 
 typedef uint16_t u16;
@@ -55,16 +62,29 @@ constexpr int DL_DMASK = 0x3FFF;   // dl: low 14 bits = d
 constexpr int DL_NONE = 0x3FFF;    // dl: no source in the frame
 constexpr int DL_LIVE = 0x8000;    // dl: live flag
 constexpr int PAR_SRC = 0xFF;      // parent code: pixel is a source
-constexpr int PAR_NONE = 0xFE;     // parent code: unreachable (frame without sources)
+constexpr int PAR_NONE = 0xFE;     // parent code: unreachable / undecided
 constexpr int MAX_HW_SUM = 8192;   // cv2's Q16 INIT_DIST0 = INT_MAX>>2 caps distances at 8191
 
-// frame facts written by k_rank: int32[FI_STRIDE] per frame
+// frame facts written by k_frame: int32[FI_STRIDE] per frame
 constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_STRIDE = 4;
 
-// cv2 tap order (OpenCV 3.4 distanceTransformEx_5x5).  0..7 forward, 8..15 backward.
-__constant__ int c_tap_di[16] = {-2, -2, -1, -1, -1, -1, -1, 0, 2, 2, 1, 1, 1, 1, 1, 0};
-__constant__ int c_tap_dj[16] = {-1, 1, -2, -1, 0, 1, 2, -1, 1, -1, 2, 1, 0, -1, -2, 1};
-__constant__ int c_tap_w[16] = {3, 3, 3, 2, 1, 2, 3, 1, 3, 3, 3, 2, 1, 2, 3, 1};
+// cv2 tap order (OpenCV 3.4 distanceTransformEx_5x5), forward taps 0..7; backward tap t is the
+// NEGATED forward tap t with the same weight.  Parent code = t | (backward ? 8 : 0).
+#define TAP_DI(t) ((t) < 2 ? -2 : (t) < 7 ? -1 : 0)
+#define TAP_DJ(t) ((t) == 0 ? -1 : (t) == 1 ? 1 : (t) == 2 ? -2 : (t) == 3 ? -1 : (t) == 4 ? 0 : (t) == 5 ? 1 : (t) == 6 ? 2 : -1)
+#define TAP_W(t) ((t) < 3 ? 3 : (t) == 3 ? 2 : (t) == 4 ? 1 : (t) == 5 ? 2 : (t) == 6 ? 3 : 1)
+constexpr u32 TAP_DI_NIB = 0x21111100u;  // nibble t = di(t) + 2
+constexpr u32 TAP_DJ_NIB = 0x14321031u;  // nibble t = dj(t) + 2
+
+__device__ __forceinline__ void tap_decode(int code, int &di, int &dj) {
+    const int sh = (code & 7) * 4;
+    di = (int)((TAP_DI_NIB >> sh) & 15u) - 2;
+    dj = (int)((TAP_DJ_NIB >> sh) & 15u) - 2;
+    if (code & 8) {
+        di = -di;
+        dj = -dj;
+    }
+}
 
 __device__ __forceinline__ int ld16(const u16 *p) {
     int v = *p;
@@ -73,60 +93,523 @@ __device__ __forceinline__ int ld16(const u16 *p) {
 __device__ __forceinline__ u16 st16(int v) { return (u16)(v >= INF16 ? INF16 : v); }
 
 // ------------------------------------------------------------------------------------------------
-// k_colscan: one lane per image column, 64 adjacent columns per wave (coalesced row reads).
-//   down sweep: gu(i,j) = rows to the nearest source at or above (i,j); ballots give the 64-pixel
-//               source / value bit words of row i.
-//   up sweep:   gd likewise from below; stores g = min(gu, gd).
-// Source predicate exactly as tools.py:8: mask = (1.0 - x) > thr  (1 = fill, 0 = source).
+// k_mask: one wave per image row.  Source predicate exactly as tools.py:8, mask = (1.0 - x) > thr
+// (1 = fill, 0 = source); value predicate as tools.py:22, x > thr.  Per 64-pixel word: the two bit
+// words and the row-local exclusive popcount; per row: totals (+ "masks differ" in bit 31).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_colscan(const float *__restrict__ x, int H, int W, int Wd,
-                                                float src_thr, float val_thr, u16 *__restrict__ gu,
-                                                u16 *__restrict__ g, u64 *__restrict__ srcbits,
-                                                u64 *__restrict__ valbits) {
+__global__ __launch_bounds__(256) void k_mask(const float *__restrict__ x, int H, int W, int Wd,
+                                              float src_thr, float val_thr, u64 *__restrict__ srcbits,
+                                              u64 *__restrict__ valbits, u16 *__restrict__ wpre_s,
+                                              u16 *__restrict__ wpre_v, u32 *__restrict__ rowcnt_s,
+                                              u32 *__restrict__ rowcnt_v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (i >= H) return;
+    const size_t rowid = (size_t)b * H + i;
+    const float *row = x + rowid * W;
+    u32 ps = 0, pv = 0, mis = 0;
+#pragma unroll 4
+    for (int k = 0; k < Wd; ++k) {
+        const int j = k * 64 + lane;
+        const float v = j < W ? row[j] : 0.0f;
+        const bool s = j < W && !((1.0f - v) > src_thr);
+        const bool isv = j < W && (v > val_thr);
+        const u64 sb = __ballot(s), vb = __ballot(isv);
+        if (lane == 0) {
+            const size_t wi = rowid * Wd + k;
+            srcbits[wi] = sb;
+            valbits[wi] = vb;
+            wpre_s[wi] = (u16)ps;
+            wpre_v[wi] = (u16)pv;
+        }
+        ps += __popcll(sb);
+        pv += __popcll(vb);
+        mis |= (sb != vb);
+    }
+    if (lane == 0) {
+        rowcnt_s[rowid] = ps;
+        rowcnt_v[rowid] = pv | (mis ? 0x80000000u : 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_frame: one workgroup per frame.  Exclusive scan of the row counts = raster rank of the first
+// source / value pixel of every row: cv2's label init (k=1; every zero pixel gets k++) and numpy's
+// boolean compaction x[with_value] (tools.py:24).  The value list is only materialised when the two
+// masks differ somewhere in the frame.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, const u64 *__restrict__ valbits,
+                                               const u16 *__restrict__ wpre_v,
+                                               const u32 *__restrict__ rowcnt_s,
+                                               const u32 *__restrict__ rowcnt_v, int H, int W, int Wd,
+                                               u32 *__restrict__ rowbase_s, u32 *__restrict__ rowbase_v,
+                                               int *__restrict__ finfo, float *__restrict__ vlist,
+                                               int *__restrict__ fflag, int *__restrict__ frame_status,
+                                               int force_general) {
+    __shared__ u32 s_ws[4], s_wv[4];
+    __shared__ int s_mis;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 *cs_ = rowcnt_s + (size_t)b * H, *cv_ = rowcnt_v + (size_t)b * H;
+    u32 *bs_ = rowbase_s + (size_t)b * H, *bv_ = rowbase_v + (size_t)b * H;
+    if (tid == 0) s_mis = 0;
+    __syncthreads();
+    u32 run_s = 0, run_v = 0;
+    int mis = 0;
+    for (int base = 0; base < H; base += 256) {
+        const int i = base + tid;
+        u32 cs = 0, cv = 0;
+        if (i < H) {
+            cs = cs_[i];
+            cv = cv_[i];
+            mis |= (int)(cv >> 31);
+            cv &= 0x7FFFFFFFu;
+        }
+        u32 is = cs, iv = cv;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            u32 ts = __shfl_up(is, off), tv = __shfl_up(iv, off);
+            if (lane >= off) {
+                is += ts;
+                iv += tv;
+            }
+        }
+        if (lane == 63) {
+            s_ws[wave] = is;
+            s_wv[wave] = iv;
+        }
+        __syncthreads();
+        u32 ps = 0, pv = 0, ts = 0, tv = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < wave) {
+                ps += s_ws[k];
+                pv += s_wv[k];
+            }
+            ts += s_ws[k];
+            tv += s_wv[k];
+        }
+        if (i < H) {
+            bs_[i] = run_s + ps + is - cs;
+            bv_[i] = run_v + pv + iv - cv;
+        }
+        run_s += ts;
+        run_v += tv;
+        __syncthreads();
+    }
+    if (mis) atomicOr(&s_mis, 1);
+    __syncthreads();
+    const int misaligned = s_mis;
+    if (tid == 0) {
+        finfo[b * FI_STRIDE + FI_NSRC] = (int)run_s;
+        finfo[b * FI_STRIDE + FI_NVAL] = (int)run_v;
+        finfo[b * FI_STRIDE + FI_MISALIGNED] = misaligned;
+        fflag[b] = force_general ? 1 : 0;
+        frame_status[b] = force_general ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
+    }
+    if (misaligned) {
+        // rare path: scatter x at value pixels into the compacted value list
+        const float *xf = x + (size_t)b * H * W;
+        float *vl = vlist + (size_t)b * H * W;
+        const int nwords = H * Wd;
+        for (int w = tid; w < nwords; w += 256) {
+            u64 vb = valbits[(size_t)b * nwords + w];
+            const int i = w / Wd, j0 = (w - i * Wd) * 64;
+            u32 k = bv_[i] + wpre_v[(size_t)b * nwords + w];
+            while (vb) {
+                const int bit = __ffsll((long long)vb) - 1;
+                vb &= vb - 1;
+                vl[k++] = xf[(size_t)i * W + j0 + bit];
+            }
+        }
+    }
+}
+
+// label of the source at (i, j): 1 + number of sources before it in raster order
+__device__ __forceinline__ int source_rank(u32 base, u64 word, int j) {
+    return (int)base + __popcll(word & ((1ull << (j & 63)) - 1ull)) + 1;
+}
+
+// gather depth_list[label-1] with numpy's index semantics (tools.py:26)
+__device__ __forceinline__ float gather_depth(const float *__restrict__ xf, const float *__restrict__ vlf,
+                                              int label, int src_pixel, int nval, int misaligned,
+                                              int *frame_status_b) {
+    int idx = label - 1;
+    if (idx < 0) idx += nval;  // numpy: index -1 wraps to the last element
+    if (idx < 0 || idx >= nval) {
+        atomicOr(frame_status_b, DTFILL_FRAME_INDEX_ERROR);
+        return nanf("");
+    }
+    if (misaligned) return vlf[idx];
+    return xf[src_pixel];  // masks agree: the label-th value IS the source pixel's own depth
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fused: one workgroup per window = tile (<= F_THM x F_TWM) + halo FR, everything in LDS.
+//   s_u : uint8 gu (column scan from above, capped at F_CAP); after the knight-line scan the same
+//         bytes hold parent codes (bit 7 set marks "this byte is a code", so no refill pass)
+//   s_x : uint8 g -> a|flag -> d|live<<7, rewritten in place by the row scans; rows/columns outside
+//         the image and a border (2 rows top/bottom, 4 columns left, next row's border on the right)
+//         stay F_BORDER = "never matches a tap"
+// In-place row scans: left-to-right a(c) = min(g(c), a(c-1)+1); right-to-left over a itself,
+// d(c) = min(a(c), d(c+1)+1), which equals min over g on both sides because a <= g and a(k)+(k-c) is
+// the length of a real path.  So g is dead after the first pass and two window arrays suffice.
+// LDS row pitch 196 B = 49 dwords (odd): lanes walking 64 different ROWS at one column hit distinct
+// banks; lanes on consecutive COLUMNS share dwords.  53.6 KB per block -> 3 blocks per CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int FR = 16;
+constexpr int F_THM = 88, F_TWM = 160;
+constexpr int F_WHM = F_THM + 2 * FR;  // 120
+constexpr int F_WWM = F_TWM + 2 * FR;  // 192
+constexpr int F_P = 196;
+constexpr int F_CAP = 100;
+// border / out-of-image value of s_x.  Must never satisfy a tap test (nv & msk) + w == d | live<<7:
+// 0x70 + w is 0x71..0x73, neither a distance < F_CAP nor 0x80 | d.  (0x7F would: 0x7F + 3 == 0x80 | 2.)
+constexpr u32 F_BORDER = 0x70;
+constexpr int F_NW = 4;   // 64-bit words a window row can touch: F_WWM/64 + 1
+constexpr int F_NT = 256; // threads per block
+constexpr int F_EB = 4;   // epilogue batch: pixels per lane walked in lockstep / gathers in flight together
+constexpr int F_RING = 4; // halo ring whose parent codes are evaluated up front with the tile's
+
+#define FU(r, c) ((r) * F_P + (c))
+#define FX(r, c) (((r) + 2) * F_P + (c) + 4)
+
+// 5x5 parent rule at window cell (rr, cc); returns PAR_SRC / PAR_NONE / 0x80 | tap code
+__device__ __forceinline__ int fused_parent(const u8 *__restrict__ s_x, int rr, int cc) {
+    const u8 *p = s_x + FX(rr, cc);
+    const int v = *p;
+    const int d = v & 0x7F;
+    if (d == 0) return PAR_SRC;
+    if (d >= F_CAP) return PAR_NONE;
+    const int live = v >> 7;
+    const int sgn = live ? 1 : -1;       // backward tap = negated forward tap
+    const int msk = live ? 0xFF : 0x7F;  // forward taps must be live themselves
+    const int want = d | (live ? 0x80 : 0);
+    int code = PAR_NONE;
+#pragma unroll
+    for (int t = 7; t >= 0; --t) {  // descending: the FIRST matching tap is kept
+        const int nv = p[sgn * (TAP_DI(t) * F_P + TAP_DJ(t))];
+        if ((nv & msk) + TAP_W(t) == want) code = t;
+    }
+    if (code == PAR_NONE) return code;
+    // encode the step itself: 0x80 | (di+2) << 3 | (dj+2), so that a hop of the walk is
+    // address += (code >> 3 & 7) * F_P + (code & 7) - (2 * F_P + 2)
+    const int di = sgn * (int)(((TAP_DI_NIB >> (4 * code)) & 15u) - 2u);
+    const int dj = sgn * (int)(((TAP_DJ_NIB >> (4 * code)) & 15u) - 2u);
+    return 0x80 | ((di + 2) << 3) | (dj + 2);
+}
+
+__global__ __launch_bounds__(F_NT) void k_fused(
+    const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
+    const u32 *__restrict__ rowbase_s, const int *__restrict__ finfo, const float *__restrict__ vlist,
+    int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
+    float *__restrict__ out_dt, int32_t *__restrict__ out_index, int *__restrict__ fflag,
+    int *__restrict__ frame_status, int stop_after) {
+    __shared__ __attribute__((aligned(16))) u8 s_u[F_WHM * F_P];
+    __shared__ __attribute__((aligned(16))) u8 s_x[(F_WHM + 4) * F_P];
+    __shared__ u64 s_sb[F_WHM * F_NW];
+    __shared__ u32 s_rk[F_WHM * F_NW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NWAVE = F_NT / 64;
+    const int b = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int r0 = ty * TH, c0 = tx * TW;
+    const int th = min(TH, H - r0), tw = min(TW, W - c0);
+    const int wr0 = r0 - FR, wc0 = c0 - FR;  // image coords of window cell (0,0)
+    const int WH = th + 2 * FR, WW = tw + 2 * FR;
+    // in-image part of the window, window coords
+    const int ra = max(0, -wr0), rb = min(WH, H - wr0);
+    const int ca = max(0, -wc0), cb = min(WW, W - wc0);
+    const int rh = rb - ra, cw = cb - ca;
+    const int w0 = wc0 >> 6;  // first 64-bit word column the window can touch (-1 if wc0 < 0)
+
+    // ---- P0: s_x = 0x7F everywhere, s_u = CAP everywhere; fetch the window's bit words + ranks
+    {
+        u32 *x32 = reinterpret_cast<u32 *>(s_x), *u32p = reinterpret_cast<u32 *>(s_u);
+        for (int k = tid; k < (F_WHM + 4) * F_P / 4; k += F_NT) x32[k] = 0x01010101u * F_BORDER;
+        for (int k = tid; k < F_WHM * F_P / 4; k += F_NT) u32p[k] = 0x01010101u * F_CAP;
+#pragma unroll 4
+        for (int idx = tid; idx < WH * F_NW; idx += F_NT) {
+            const int r = idx >> 2, k = idx & 3;
+            const int gi = wr0 + r, w = w0 + k;
+            u64 sb = 0;
+            u32 rk = 0;
+            if (gi >= 0 && gi < H && w >= 0 && w < Wd) {
+                const size_t wi = ((size_t)b * H + gi) * Wd + w;
+                sb = srcbits[wi];
+                rk = rowbase_s[(size_t)b * H + gi] + wpre_s[wi];
+            }
+            s_sb[idx] = sb;
+            s_rk[idx] = rk;
+        }
+    }
+    __syncthreads();
+
+    if (stop_after == 0) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
+    // ---- P1: column scans, one lane per window column: gu -> s_u, g = min(gu, gd) -> s_x
+    for (int c = ca + tid; c < cb; c += F_NT) {
+        const int gj = wc0 + c;
+        const u32 *sb32 = reinterpret_cast<const u32 *>(s_sb) + ((((gj >> 6) - w0) << 1) | ((gj >> 5) & 1));
+        const int bit = gj & 31;
+        int up = F_CAP;
+#pragma unroll 8
+        for (int r = ra; r < rb; ++r) {
+            const u32 s = (sb32[r * (2 * F_NW)] >> bit) & 1u;
+            up = s ? 0 : min(up + 1, F_CAP);
+            s_u[FU(r, c)] = (u8)up;
+        }
+        int dn = F_CAP;
+#pragma unroll 8
+        for (int r = rb - 1; r >= ra; --r) {
+            const u32 s = (sb32[r * (2 * F_NW)] >> bit) & 1u;
+            dn = s ? 0 : min(dn + 1, F_CAP);
+            s_x[FX(r, c)] = (u8)min((int)s_u[FU(r, c)], dn);
+        }
+    }
+    __syncthreads();
+
+    if (stop_after == 1) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
+    // ---- P2: row scans, one lane per window row, four cells (one dword) per step, in place in s_x.
+    // Pass 1 keeps a and the flag (dA == a); pass 2: d, liveA = flag && (a == d)  [dA >= a >= d].
+    if (tid < rh) {
+        const int r = ra + tid;
+        u32 *xr = reinterpret_cast<u32 *>(s_x + FX(r, 0));
+        const u32 *ur = reinterpret_cast<const u32 *>(s_u + FU(r, 0));
+        const int k0 = ca >> 2, k1 = (cb + 3) >> 2;
+        int a = F_CAP, dA = F_CAP;
+#pragma unroll 2
+        for (int k = k0; k < k1; ++k) {
+            const u32 g4 = xr[k], u4 = ur[k];
+            u32 out = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int g = (g4 >> (8 * t)) & 0xFF, u = (u4 >> (8 * t)) & 0xFF;
+                a = min(g, a + 1);
+                dA = min(u, dA + 1);
+                out |= (u32)(a | (dA == a ? 0x80 : 0)) << (8 * t);
+            }
+            // cells of an edge dword that lie outside the image keep F_BORDER
+            const int cl = 4 * k;
+            u32 keep = 0xFFFFFFFFu;
+            if (cl < ca) keep &= 0xFFFFFFFFu << (8 * (ca - cl));
+            if (cl + 4 > cb) keep &= 0xFFFFFFFFu >> (8 * (cl + 4 - cb));
+            xr[k] = (out & keep) | ((0x01010101u * F_BORDER) & ~keep);
+        }
+        int d = F_CAP;
+#pragma unroll 2
+        for (int k = k1 - 1; k >= k0; --k) {
+            const u32 v4 = xr[k];
+            u32 out = 0;
+#pragma unroll
+            for (int t = 3; t >= 0; --t) {
+                const int v = (v4 >> (8 * t)) & 0xFF;
+                const int av = v & 0x7F;
+                const int dn = d + 1;
+                d = min(av, dn);
+                const int live = (v >> 7) & (av <= dn) & (d < F_CAP);
+                out |= (u32)(d | (live << 7)) << (8 * t);
+            }
+            const int cl = 4 * k;
+            u32 keep = 0xFFFFFFFFu;
+            if (cl < ca) keep &= 0xFFFFFFFFu << (8 * (ca - cl));
+            if (cl + 4 > cb) keep &= 0xFFFFFFFFu >> (8 * (cl + 4 - cb));
+            xr[k] = (out & keep) | ((0x01010101u * F_BORDER) & ~keep);
+        }
+    }
+    __syncthreads();
+
+    if (stop_after == 2) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
+    // ---- P3: knight-line scan, one lane per line u = c + 2 r over columns [0, cw] (column cw is the
+    // virtual one right of the window/image edge: E = gu(.,cw-1) - 1).  Sets live where dB == d.
+    // The scan itself only loads (so the loads of unrolled steps overlap); the rows where dB == d are
+    // remembered as bits and the live flags are stored afterwards.
+    {
+        const int nU = cw + 1 + 2 * (rh - 1);
+        for (int ub = wave * 64; ub < nU; ub += F_NT) {
+            const int u = ub + lane;
+            const int u1 = min(ub + 63, nU - 1);
+            const int rlo = max(0, (ub - cw + 1) / 2), rhi = min(rh - 1, u1 / 2);
+            int D = 4 * F_CAP;
+            u64 hit0 = 0, hit1 = 0;  // bit (r2 - rlo): rows rlo..rlo+63 / rlo+64..rlo+127
+#pragma unroll 4
+            for (int r2 = rlo; r2 <= rhi; ++r2) {
+                const int c2 = u - 2 * r2;
+                const bool on = u < nU && c2 >= 0 && c2 <= cw;
+                const int rr = ra + r2;
+                const int cA = ca + min(max(c2, 0), cw - 1), cB = ca + min(max(c2 - 1, 0), cw - 1);
+                const int eA = s_u[FU(rr, cA)], eB = s_u[FU(rr, cB)], v = s_x[FX(rr, cA)];
+                const int dbv = D + 3;
+                int e = (on && c2 < cw) ? eA : 4 * F_CAP;
+                if (on && c2 >= 1) e = min(e, eB - 1);
+                const bool hit = on && c2 < cw && v == dbv && dbv < F_CAP;  // v == dbv: v has no live bit
+                const int k = r2 - rlo;
+                if (k < 64)
+                    hit0 |= (u64)hit << k;
+                else
+                    hit1 |= (u64)hit << (k - 64);
+                D = on ? min(min(e, dbv), 4 * F_CAP) : 4 * F_CAP;
+            }
+            while (hit0) {
+                const int k = __ffsll((long long)hit0) - 1;
+                hit0 &= hit0 - 1;
+                s_x[FX(ra + rlo + k, ca + u - 2 * (rlo + k))] |= 0x80;
+            }
+            while (hit1) {
+                const int k = 64 + __ffsll((long long)hit1) - 1;
+                hit1 &= hit1 - 1;
+                s_x[FX(ra + rlo + k, ca + u - 2 * (rlo + k))] |= 0x80;
+            }
+        }
+    }
+    __syncthreads();
+    if (stop_after == 3) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
+
+    // ---- P4: parent codes of the tile cells and a ring of F_RING halo cells around them (gu is dead:
+    // the codes overwrite it; a byte < 0x80 is a leftover gu value = "not evaluated yet", which the
+    // rest of the halo stays until a chain reaches it)
+    u8 *s_par = s_u;
+    {
+        const int pr0 = max(ra, FR - F_RING), pr1 = min(rb, FR + th + F_RING);
+        const int pc0 = max(ca, FR - F_RING), pc1 = min(cb, FR + tw + F_RING);
+        for (int cc = pc0 + lane; cc < pc1; cc += 64) {
+#pragma unroll 4
+            for (int rr = pr0 + wave; rr < pr1; rr += NWAVE) s_par[FU(rr, cc)] = (u8)fused_parent(s_x, rr, cc);
+        }
+    }
+    __syncthreads();
+    if (stop_after == 4) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
+
+    // ---- P5: tile pixels: walk to the source, rank -> label, gather, store.  Each lane walks F_EB
+    // pixels in lockstep (their LDS reads are independent, so the hop latencies overlap) and then has
+    // F_EB global gathers in flight together.
+    const size_t fo = (size_t)b * H * W;
+    const int nval = finfo[b * FI_STRIDE + FI_NVAL];
+    const int misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
+    bool overflow = false;
+    for (int tc = lane; tc < tw; tc += 64) {
+        const int cc = FR + tc;
+        for (int trb = wave; trb < th; trb += NWAVE * F_EB) {
+            int pos[F_EB], code[F_EB], dd[F_EB];  // pos = FU(row, col): linear LDS index of the walker
+            bool ok[F_EB];
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) {
+                const int tr = trb + e * NWAVE;
+                const int rr = FR + min(tr, th - 1);
+                const int d = s_x[FX(rr, cc)] & 0x7F;
+                dd[e] = d;
+                ok[e] = tr < th && d <= FR;
+                if (tr < th && d > FR) overflow = true;  // undecidable here: the frame takes the general path
+                pos[e] = FU(rr, cc);
+                code[e] = ok[e] ? (int)s_par[FU(rr, cc)] : PAR_NONE;
+            }
+            for (int hop = 0; hop <= FR; ++hop) {
+                bool moving = false;
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) {
+                    int c = code[e];
+                    if (c < 0x80) {  // halo cell nobody has evaluated yet
+                        const int r_ = pos[e] / F_P;
+                        c = fused_parent(s_x, r_, pos[e] - r_ * F_P);
+                        s_par[pos[e]] = (u8)c;  // same value from every writer
+                    }
+                    if (c < PAR_NONE) {
+                        pos[e] += ((c >> 3) & 7) * F_P + (c & 7) - (2 * F_P + 2);
+                        c = s_par[pos[e]];
+                        moving = true;
+                    }
+                    code[e] = c;
+                }
+                if (!__any(moving)) break;
+            }
+            if (stop_after == 5) {  // timing only: keep the walk alive, skip the rest
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(pos[e]));
+                continue;
+            }
+            int lab[F_EB], spx[F_EB];
+            float val[F_EB];
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) {
+                // a valid chain ends on a source inside the in-image window; the clamps only make sure
+                // that a logic error could never become a wild global access
+                const int pr_ = pos[e] / F_P, pc_ = pos[e] - pr_ * F_P;
+                const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
+                const int gj = wc0 + c_;
+                const int k = (gj >> 6) - w0;
+                lab[e] = source_rank(s_rk[r_ * F_NW + k], s_sb[r_ * F_NW + k], gj);
+                spx[e] = (wr0 + r_) * W + gj;
+            }
+            if (stop_after == 6) {
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(lab[e]), "v"(spx[e]));
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e)
+                if (ok[e] && out_depth)
+                    val[e] = gather_depth(x + fo, vlist + fo, lab[e], spx[e], nval, misaligned, frame_status + b);
+            if (stop_after == 7) {
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(val[e]));
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) {
+                if (!ok[e]) continue;
+                const size_t o = fo + (size_t)(r0 + trb + e * NWAVE) * W + (c0 + tc);
+                if (out_index) out_index[o] = lab[e];
+                if (out_dt) out_dt[o] = (float)dd[e];
+                if (out_depth) out_depth[o] = val[e];
+            }
+        }
+    }
+    if (overflow) {
+        fflag[b] = 1;  // same-value race
+        atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);
+    }
+}
+
+// ================================================================================================
+// General path (any distance).  Every kernel returns at once for frames k_fused did not flag.
+// ================================================================================================
+
+// k_colscan: one lane per image column, 64 adjacent columns per wave.
+//   down sweep: gu(i,j) = rows to the nearest source at or above (i,j); up sweep: g = min(gu, gd).
+__global__ __launch_bounds__(64) void k_colscan(const u64 *__restrict__ srcbits, const int *__restrict__ fflag,
+                                                int H, int W, int Wd, u16 *__restrict__ gu,
+                                                u16 *__restrict__ g) {
     const int b = blockIdx.y, wd = blockIdx.x, lane = threadIdx.x;
+    if (!fflag[b]) return;
     const int j = wd * 64 + lane;
     const bool inb = j < W;
     const size_t fo = (size_t)b * H * W;
-    const float *xf = x + fo;
     u16 *guf = gu + fo, *gf = g + fo;
-    u64 *sbf = srcbits + (size_t)b * H * Wd, *vbf = valbits + (size_t)b * H * Wd;
+    const u64 *sbf = srcbits + (size_t)b * H * Wd + wd;
 
     int up = BIG;
-#pragma unroll 4
     for (int i = 0; i < H; ++i) {
-        float v = inb ? xf[(size_t)i * W + j] : 0.0f;
-        bool s = inb && !((1.0f - v) > src_thr);
-        bool isv = inb && (v > val_thr);
-        u64 sb = __ballot(s), vb = __ballot(isv);
-        if (lane == 0) {
-            sbf[(size_t)i * Wd + wd] = sb;
-            vbf[(size_t)i * Wd + wd] = vb;
-        }
+        const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
         up = s ? 0 : min(up + 1, BIG);
         if (inb) guf[(size_t)i * W + j] = st16(up);
     }
     int dn = BIG;
-#pragma unroll 4
     for (int i = H - 1; i >= 0; --i) {
-        float v = inb ? xf[(size_t)i * W + j] : 0.0f;
-        bool s = inb && !((1.0f - v) > src_thr);
+        const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
         dn = s ? 0 : min(dn + 1, BIG);
         if (inb) {
-            int u = ld16(guf + (size_t)i * W + j);
+            const int u = ld16(guf + (size_t)i * W + j);
             gf[(size_t)i * W + j] = st16(min(u, dn));
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------
 // k_skew: one lane per knight line u = j + 2 i over the extended column range j in [0, W]
-// (column W is virtual: E(i,W) = gu(i,W-1) - 1, needed for a source one column right of the edge
-// pixel's up-right neighbour).  All lanes of a wave sit in the same image row at each step, so
-// the gu reads and dB writes of a step are contiguous.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_skew(const u16 *__restrict__ gu, int H, int W,
-                                             u16 *__restrict__ dB) {
+// (column W is virtual: E(i,W) = gu(i,W-1) - 1).  All lanes of a wave sit in the same image row at
+// each step, so the gu reads and dB writes of a step are contiguous.
+__global__ __launch_bounds__(64) void k_skew(const u16 *__restrict__ gu, const int *__restrict__ fflag,
+                                             int H, int W, u16 *__restrict__ dB) {
     const int b = blockIdx.y, lane = threadIdx.x;
+    if (!fflag[b]) return;
     const int nU = W + 2 * (H - 1) + 1;
     const int u0 = blockIdx.x * 64;
     const int u = u0 + lane;
@@ -158,102 +641,9 @@ __global__ __launch_bounds__(64) void k_skew(const u16 *__restrict__ gu, int H, 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_rank: one workgroup per frame.  Exclusive prefix popcount over the frame's bit words gives the
-// raster rank of every source (cv2's label init: k=1; every zero pixel gets k++) and of every value
-// pixel (numpy boolean compaction x[with_value], tools.py:24).  The value list itself is only
-// materialised when the two masks differ somewhere in the frame; otherwise depth_list[lbl-1] is
-// x at the source pixel itself.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rank(const float *__restrict__ x, const u64 *__restrict__ srcbits,
-                                              const u64 *__restrict__ valbits, int H, int W, int Wd,
-                                              u32 *__restrict__ srcbase, u32 *__restrict__ valbase,
-                                              int *__restrict__ finfo, float *__restrict__ vlist,
-                                              int *__restrict__ frame_status) {
-    __shared__ u32 s_ws[4], s_wv[4];
-    __shared__ int s_mis;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nwords = H * Wd;
-    const u64 *sbf = srcbits + (size_t)b * nwords, *vbf = valbits + (size_t)b * nwords;
-    u32 *sbase = srcbase + (size_t)b * nwords, *vbase = valbase + (size_t)b * nwords;
-    if (tid == 0) s_mis = 0;
-    __syncthreads();
-
-    u32 run_s = 0, run_v = 0;
-    int mis = 0;
-    for (int base = 0; base < nwords; base += 256) {
-        const int w = base + tid;
-        u64 sb = 0, vb = 0;
-        if (w < nwords) {
-            sb = sbf[w];
-            vb = vbf[w];
-        }
-        mis |= (sb != vb);
-        u32 cs = __popcll(sb), cv = __popcll(vb);
-        u32 is = cs, iv = cv;  // inclusive wave scans
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            u32 ts = __shfl_up(is, off), tv = __shfl_up(iv, off);
-            if (lane >= off) {
-                is += ts;
-                iv += tv;
-            }
-        }
-        if (lane == 63) {
-            s_ws[wave] = is;
-            s_wv[wave] = iv;
-        }
-        __syncthreads();
-        u32 ps = 0, pv = 0, ts = 0, tv = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k < wave) {
-                ps += s_ws[k];
-                pv += s_wv[k];
-            }
-            ts += s_ws[k];
-            tv += s_wv[k];
-        }
-        if (w < nwords) {
-            sbase[w] = run_s + ps + is - cs;
-            vbase[w] = run_v + pv + iv - cv;
-        }
-        run_s += ts;
-        run_v += tv;
-        __syncthreads();
-    }
-    if (mis) atomicOr(&s_mis, 1);
-    __syncthreads();
-    const int misaligned = s_mis;
-    if (tid == 0) {
-        finfo[b * FI_STRIDE + FI_NSRC] = (int)run_s;
-        finfo[b * FI_STRIDE + FI_NVAL] = (int)run_v;
-        finfo[b * FI_STRIDE + FI_MISALIGNED] = misaligned;
-        if (frame_status) frame_status[b] = DTFILL_FRAME_OK;
-    }
-    if (misaligned) {
-        // rare path: scatter x at value pixels into the compacted value list
-        const float *xf = x + (size_t)b * H * W;
-        float *vl = vlist + (size_t)b * H * W;
-        for (int w = tid; w < nwords; w += 256) {
-            u64 vb = vbf[w];
-            u32 k = vbase[w];
-            const int i = w / Wd, j0 = (w % Wd) * 64;
-            while (vb) {
-                int bit = __ffsll((long long)vb) - 1;
-                vb &= vb - 1;
-                vl[k++] = xf[(size_t)i * W + j0 + bit];
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // k_rowscan: one wave per image row.  d(i,j) = min_k g(i,k) + |j-k| as prefix-min of (g-k) plus
 // suffix-min of (g+k); dA as prefix-min of (gu-k).  64-pixel groups are scanned with wave shuffles,
-// the group-to-group carry is a wave-uniform scalar.  The left-to-right results wait in a lane-
-// private LDS slot until the right-to-left pass meets them.
-// ------------------------------------------------------------------------------------------------
+// the group-to-group carry is a wave-uniform scalar.
 __device__ __forceinline__ int wave_prefix_min(int v, int lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -272,12 +662,12 @@ __device__ __forceinline__ int wave_suffix_min(int v, int lane) {
 }
 
 __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, const u16 *__restrict__ gu,
-                                                 const u16 *__restrict__ dB, int H, int W, int ngroups,
-                                                 u16 *__restrict__ dl) {
+                                                 const u16 *__restrict__ dB, const int *__restrict__ fflag,
+                                                 int H, int W, int ngroups, u16 *__restrict__ dl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * (blockDim.x >> 6) + wave, b = blockIdx.y;
-    if (i >= H) return;  // wave-uniform; no block-level barrier below
+    if (!fflag[b] || i >= H) return;  // wave-uniform; no block-level barrier below
     u16 *s_a = reinterpret_cast<u16 *>(smem) + (size_t)wave * ngroups * 128;  // [ngroups*64] a, then dA
     u16 *s_dA = s_a + ngroups * 64;
     const size_t ro = ((size_t)b * H + i) * W;
@@ -310,7 +700,7 @@ __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, cons
                 out = DL_NONE;  // no source anywhere in the frame
             } else {
                 int dbv = ld16(dBrow + idx);
-                bool live = (s_dA[idx] == d) || (dbv == d);
+                bool live = (ld16(s_dA + idx) == d) || (dbv == d);
                 out = d | (live ? DL_LIVE : 0);
             }
             dl[ro + idx] = (u16)out;
@@ -318,17 +708,16 @@ __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, cons
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_parent: the 5x5 rule.  One byte per pixel: tap index (0..7 forward / 8..15 backward, cv2 order),
-// PAR_SRC for sources, PAR_NONE when the frame has no source.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_parent(const u16 *__restrict__ dl, int H, int W,
-                                                u8 *__restrict__ par) {
+constexpr int G_PPT = 16;  // pixels per thread in k_parent / k_resolve (keeps their no-op grids small)
+
+// k_parent: the 5x5 rule, full frame through L2.
+__global__ __launch_bounds__(256) void k_parent(const u16 *__restrict__ dl, const int *__restrict__ fflag,
+                                                int H, int W, u8 *__restrict__ par) {
     const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= H * W) return;
+    if (!fflag[b]) return;
     const size_t fo = (size_t)b * H * W;
     const u16 *dlf = dl + fo;
+    for (int p = blockIdx.x * (256 * G_PPT) + threadIdx.x, n = 0; n < G_PPT && p < H * W; ++n, p += 256) {
     const int q = dlf[p];
     const int d = q & DL_DMASK;
     int code;
@@ -339,70 +728,56 @@ __global__ __launch_bounds__(256) void k_parent(const u16 *__restrict__ dl, int 
     } else {
         const int i = p / W, j = p - i * W;
         const int live = (q & DL_LIVE) ? 1 : 0;
-        const int t0 = live ? 0 : 8;
+        const int sgn = live ? 1 : -1;
         code = PAR_NONE;
 #pragma unroll
         for (int t = 7; t >= 0; --t) {  // descending so the FIRST matching tap is the one kept
-            const int r = i + c_tap_di[t0 + t], c = j + c_tap_dj[t0 + t];
+            const int r = i + sgn * TAP_DI(t), c = j + sgn * TAP_DJ(t);
             if (r >= 0 && r < H && c >= 0 && c < W) {
                 const int v = dlf[r * W + c];
-                const bool ok = ((v & DL_DMASK) + c_tap_w[t0 + t] == d) && (!live || (v & DL_LIVE));
-                if (ok) code = t0 + t;
+                const bool ok = ((v & DL_DMASK) + TAP_W(t) == d) && (!live || (v & DL_LIVE));
+                if (ok) code = t | (live ? 0 : 8);
             }
         }
     }
     par[fo + p] = (u8)code;
+    }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_resolve: walk the parent chain to its source, turn the source pixel into cv2's label (raster
-// rank from the bit words), gather the depth (tools.py:26, numpy index semantics) and store the
-// three outputs.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_resolve(const float *__restrict__ x, const u16 *__restrict__ dl,
-                                                 const u8 *__restrict__ par, const u64 *__restrict__ srcbits,
-                                                 const u32 *__restrict__ srcbase, const int *__restrict__ finfo,
-                                                 const float *__restrict__ vlist, int H, int W, int Wd,
-                                                 float *__restrict__ out_depth, float *__restrict__ out_dt,
-                                                 int32_t *__restrict__ out_index,
-                                                 int *__restrict__ frame_status) {
+// k_resolve: walk the parent chain to its source, label, gather, store.
+__global__ __launch_bounds__(256) void k_resolve(
+    const float *__restrict__ x, const u16 *__restrict__ dl, const u8 *__restrict__ par,
+    const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
+    const int *__restrict__ finfo, const float *__restrict__ vlist, const int *__restrict__ fflag, int H,
+    int W, int Wd, float *__restrict__ out_depth, float *__restrict__ out_dt,
+    int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
     const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= H * W) return;
+    if (!fflag[b]) return;
     const size_t fo = (size_t)b * H * W;
     const u8 *parf = par + fo;
-
+    for (int p = blockIdx.x * (256 * G_PPT) + threadIdx.x, n = 0; n < G_PPT && p < H * W; ++n, p += 256) {
     int q = p;
     int code = parf[q];
     for (int hop = 0; code < 16 && hop < MAX_HW_SUM; ++hop) {
-        q += c_tap_di[code] * W + c_tap_dj[code];
+        int di, dj;
+        tap_decode(code, di, dj);
+        q = min(max(q + di * W + dj, 0), H * W - 1);  // clamp: a logic error must not become a wild access
         code = parf[q];
     }
     int label = 0;
     if (code == PAR_SRC) {
         const int i = q / W, j = q - i * W;
         const size_t w = ((size_t)b * H + i) * Wd + (j >> 6);
-        label = (int)srcbase[w] + __popcll(srcbits[w] & ((1ull << (j & 63)) - 1ull)) + 1;
+        label = source_rank(rowbase_s[(size_t)b * H + i] + wpre_s[w], srcbits[w], j);
     }
     if (out_index) out_index[fo + p] = label;
     if (out_dt) {
         const int d = dl[fo + p] & DL_DMASK;
         out_dt[fo + p] = d == DL_NONE ? 8192.0f : (float)d;  // float(INIT_DIST0 * 2^-16) == 8192.0f
     }
-    if (out_depth) {
-        const int nval = finfo[b * FI_STRIDE + FI_NVAL];
-        int idx = label - 1;
-        if (idx < 0) idx += nval;  // numpy: index -1 wraps to the last element
-        float v;
-        if (idx < 0 || idx >= nval) {
-            v = nanf("");
-            if (frame_status) frame_status[b] = DTFILL_FRAME_INDEX_ERROR;  // benign same-value race
-        } else if (finfo[b * FI_STRIDE + FI_MISALIGNED]) {
-            v = vlist[fo + idx];
-        } else {
-            v = x[fo + q];  // masks agree: the label-th value IS the source pixel's own depth
-        }
-        out_depth[fo + p] = v;
+    if (out_depth)
+        out_depth[fo + p] = gather_depth(x + fo, vlist + fo, label, q, finfo[b * FI_STRIDE + FI_NVAL],
+                                         finfo[b * FI_STRIDE + FI_MISALIGNED], frame_status + b);
     }
 }
 
@@ -415,8 +790,9 @@ struct Carve {
     u16 *gu, *g, *dB, *dl;
     u8 *par;
     u64 *srcbits, *valbits;
-    u32 *srcbase, *valbase;
-    int *finfo;
+    u16 *wpre_s, *wpre_v;
+    u32 *rowcnt_s, *rowcnt_v, *rowbase_s, *rowbase_v;
+    int *finfo, *fflag, *status;
     float *vlist;
     size_t total;
 };
@@ -425,6 +801,7 @@ Carve carve(void *ws, int B, int H, int W) {
     const size_t N = (size_t)B * H * W;
     const size_t Wd = (size_t)(W + 63) / 64;
     const size_t NW = (size_t)B * H * Wd;
+    const size_t NR = (size_t)B * H;
     char *p = static_cast<char *>(ws);
     size_t off = 0;
     Carve c;
@@ -433,16 +810,23 @@ Carve carve(void *ws, int B, int H, int W) {
         off += align256(bytes);
         return r;
     };
+    c.srcbits = (u64 *)take(NW * 8);
+    c.valbits = (u64 *)take(NW * 8);
+    c.wpre_s = (u16 *)take(NW * 2);
+    c.wpre_v = (u16 *)take(NW * 2);
+    c.rowcnt_s = (u32 *)take(NR * 4);
+    c.rowcnt_v = (u32 *)take(NR * 4);
+    c.rowbase_s = (u32 *)take(NR * 4);
+    c.rowbase_v = (u32 *)take(NR * 4);
+    c.finfo = (int *)take((size_t)B * FI_STRIDE * 4);
+    c.fflag = (int *)take((size_t)B * 4);
+    c.status = (int *)take((size_t)B * 4);
+    // general-path arrays (touched only for frames the fused kernel flags)
     c.gu = (u16 *)take(N * 2);
     c.g = (u16 *)take(N * 2);
     c.dB = (u16 *)take(N * 2);
     c.dl = (u16 *)take(N * 2);
     c.par = (u8 *)take(N);
-    c.srcbits = (u64 *)take(NW * 8);
-    c.valbits = (u64 *)take(NW * 8);
-    c.srcbase = (u32 *)take(NW * 4);
-    c.valbase = (u32 *)take(NW * 4);
-    c.finfo = (int *)take((size_t)B * FI_STRIDE * 4);
     c.vlist = (float *)take(N * 4);
     c.total = off;
     return c;
@@ -450,47 +834,65 @@ Carve carve(void *ws, int B, int H, int W) {
 
 bool shape_ok(int B, int H, int W) {
     return B >= 1 && H >= 1 && W >= 1 && (long long)H + W - 2 < MAX_HW_SUM &&
-           (long long)B * H * W < (1ll << 40);
+           (long long)B * H * W < (1ll << 31);
 }
 
-constexpr int NK_L1 = 6;
-const char *const kNamesL1[NK_L1] = {"k_colscan", "k_skew", "k_rank", "k_rowscan", "k_parent", "k_resolve"};
+constexpr int NK_L1 = 8;
+const char *const kNamesL1[NK_L1] = {"k_mask",  "k_frame",   "k_fused",  "k_colscan",
+                                     "k_skew",  "k_rowscan", "k_parent", "k_resolve"};
 
 int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, float *out_depth,
-           float *out_dt, int32_t *out_index, int32_t *frame_status, void *workspace,
+           float *out_dt, int32_t *out_index, int32_t *frame_status, void *workspace, unsigned flags,
            hipStream_t st, hipEvent_t *ev) {
     const Carve c = carve(workspace, B, H, W);
     const int Wd = (W + 63) / 64;
     const int N1 = H * W;
+    int *status = frame_status ? frame_status : c.status;
+    const bool general_only = flags & DTFILL_FLAG_GENERAL_ONLY;
+    const bool fused_only = flags & DTFILL_FLAG_FUSED_ONLY;
+    // debug: DTFILL_FUSED_STOP=n makes k_fused return after phase n (timing only, outputs undefined)
+    const char *stop_env = ev ? getenv("DTFILL_FUSED_STOP") : nullptr;
+    const int fused_stop = stop_env ? atoi(stop_env) : -1;
     int k = 0;
     auto mark = [&]() {
-        if (ev) hipEventRecord(ev[k++], st);
+        if (ev) (void)hipEventRecord(ev[k++], st);
     };
     mark();
-    k_colscan<<<dim3(Wd, B), 64, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.gu, c.g, c.srcbits, c.valbits);
+    k_mask<<<dim3((H + 3) / 4, B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits,
+                                                c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v);
     mark();
-    {
-        const int nU = W + 2 * (H - 1) + 1;
-        k_skew<<<dim3((nU + 63) / 64, B), 64, 0, st>>>(c.gu, H, W, c.dB);
+    k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s,
+                               c.rowbase_v, c.finfo, c.vlist, c.fflag, status, general_only ? 1 : 0);
+    mark();
+    if (!general_only) {
+        const int nty = (H + F_THM - 1) / F_THM, ntx = (W + F_TWM - 1) / F_TWM;
+        const int TH = (H + nty - 1) / nty, TW = (W + ntx - 1) / ntx;  // even split, <= F_THM x F_TWM
+        k_fused<<<dim3(ntx * nty, B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H,
+                                                   W, Wd, TH, TW, ntx, out_depth, out_dt, out_index,
+                                                   c.fflag, status, fused_stop);
     }
     mark();
-    k_rank<<<B, 256, 0, st>>>(x, c.srcbits, c.valbits, H, W, Wd, c.srcbase, c.valbase, c.finfo, c.vlist,
-                              frame_status);
-    mark();
-    {
+    if (!fused_only) {
+        k_colscan<<<dim3(Wd, B), 64, 0, st>>>(c.srcbits, c.fflag, H, W, Wd, c.gu, c.g);
+        mark();
+        const int nU = W + 2 * (H - 1) + 1;
+        k_skew<<<dim3((nU + 63) / 64, B), 64, 0, st>>>(c.gu, c.fflag, H, W, c.dB);
+        mark();
         const int ngroups = Wd;
         const size_t per_wave = (size_t)ngroups * 128 * sizeof(u16);  // <= 32 KiB at W = 8191
         const int wpb = (int)max((size_t)1, min((size_t)4, (size_t)65536 / per_wave));
-        k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, H, W,
-                                                                              ngroups, c.dl);
+        k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag, H,
+                                                                              W, ngroups, c.dl);
+        mark();
+        k_parent<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(c.dl, c.fflag, H, W, c.par);
+        mark();
+        k_resolve<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(x, c.dl, c.par, c.srcbits, c.wpre_s,
+                                                            c.rowbase_s, c.finfo, c.vlist, c.fflag, H, W, Wd,
+                                                            out_depth, out_dt, out_index, status);
+        mark();
+    } else {
+        for (int t = 0; t < 5; ++t) mark();
     }
-    mark();
-    k_parent<<<dim3((N1 + 255) / 256, B), 256, 0, st>>>(c.dl, H, W, c.par);
-    mark();
-    k_resolve<<<dim3((N1 + 255) / 256, B), 256, 0, st>>>(x, c.dl, c.par, c.srcbits, c.srcbase, c.finfo,
-                                                        c.vlist, H, W, Wd, out_depth, out_dt, out_index,
-                                                        frame_status);
-    mark();
     return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
 
@@ -514,7 +916,7 @@ const char *dtfill_strerror(int code) {
     switch (code) {
         case DTFILL_OK: return "ok";
         case DTFILL_ERR_NULL: return "null input, workspace, or no output requested";
-        case DTFILL_ERR_SHAPE: return "bad shape: need B,H,W >= 1 and H+W-2 < 8192";
+        case DTFILL_ERR_SHAPE: return "bad shape: need B,H,W >= 1, H+W-2 < 8192 and B*H*W < 2^31";
         case DTFILL_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
         case DTFILL_ERR_METRIC: return "unknown metric";
         case DTFILL_ERR_LAUNCH: return "HIP kernel launch failed";
@@ -529,13 +931,20 @@ size_t dtfill_workspace_bytes(int B, int H, int W, int metric) {
     return carve(nullptr, B, H, W).total;
 }
 
+int dtfill_batch_flags(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
+                       float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
+                       void *workspace, size_t ws_bytes, void *stream, unsigned flags) {
+    int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes);
+    if (rc != DTFILL_OK) return rc;
+    return run_l1(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags,
+                  static_cast<hipStream_t>(stream), nullptr);
+}
+
 int dtfill_batch(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
                  float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
                  void *workspace, size_t ws_bytes, void *stream) {
-    int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes);
-    if (rc != DTFILL_OK) return rc;
-    return run_l1(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace,
-                  static_cast<hipStream_t>(stream), nullptr);
+    return dtfill_batch_flags(x, B, H, W, src_thr, val_thr, metric, out_depth, out_dt, out_index,
+                              frame_status, workspace, ws_bytes, stream, 0u);
 }
 
 int dtfill_num_kernels(int metric) { return metric == DTFILL_METRIC_L1_CV ? NK_L1 : 0; }
@@ -547,7 +956,7 @@ const char *dtfill_kernel_name(int metric, int k) {
 
 int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
                        float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
-                       void *workspace, size_t ws_bytes, void *stream, float *kernel_ms) {
+                       void *workspace, size_t ws_bytes, void *stream, unsigned flags, float *kernel_ms) {
     int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes);
     if (rc != DTFILL_OK) return rc;
     if (!kernel_ms) return DTFILL_ERR_NULL;
@@ -555,10 +964,11 @@ int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float
     hipEvent_t ev[NK_L1 + 1];
     for (int k = 0; k <= NK_L1; ++k)
         if (hipEventCreate(&ev[k]) != hipSuccess) return DTFILL_ERR_NO_DEVICE;
-    rc = run_l1(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, st, ev);
-    hipEventSynchronize(ev[NK_L1]);
-    for (int k = 0; k < NK_L1; ++k) hipEventElapsedTime(&kernel_ms[k], ev[k], ev[k + 1]);
-    for (int k = 0; k <= NK_L1; ++k) hipEventDestroy(ev[k]);
+    rc = run_l1(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags,
+                st, ev);
+    (void)hipEventSynchronize(ev[NK_L1]);
+    for (int k = 0; k < NK_L1; ++k) (void)hipEventElapsedTime(&kernel_ms[k], ev[k], ev[k + 1]);
+    for (int k = 0; k <= NK_L1; ++k) (void)hipEventDestroy(ev[k]);
     return rc;
 }
 

@@ -63,10 +63,12 @@ class DtFill:
         return int(self.lib.dtfill_workspace_bytes(B, H, W, self.metric))
 
     # -- the op --------------------------------------------------------------------------------
-    def run(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL, timed=False):
+    def run(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL, timed=False, path="auto"):
         """x: float32 CUDA tensor [B,H,W] (contiguous).  Returns a dict of device tensors
         (views of buffers owned by this object, overwritten by the next call) for the names in
-        `want`, plus "status" (int32 [B]).  Asynchronous on the current stream unless timed."""
+        `want`, plus "status" (int32 [B], bit set of _lib.FRAME_*).  Asynchronous on the current
+        stream unless timed.  path: "auto" (fused LDS-tile kernel, general kernels for frames it
+        flags), "general" or "fused" (tests / benchmarks)."""
         if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 3 or not x.is_contiguous():
             raise ValueError("x must be a contiguous float32 CUDA tensor [B,H,W]")
         B, H, W = x.shape
@@ -82,14 +84,15 @@ class DtFill:
                 ptr("depth"), ptr("dt"), ptr("index"), o["status"].data_ptr(),
                 self._ws.data_ptr() + self._ws_off, self._ws_bytes, stream,
             ]
+            flags = _lib.PATHS[path]
             if timed:
                 nk = self.lib.dtfill_num_kernels(self.metric)
                 ms = (ctypes.c_float * nk)()
-                _lib.check(self.lib.dtfill_batch_timed(*args, ctypes.cast(ms, ctypes.c_void_p)))
+                _lib.check(self.lib.dtfill_batch_timed(*args, flags, ctypes.cast(ms, ctypes.c_void_p)))
                 names = [self.lib.dtfill_kernel_name(self.metric, k).decode() for k in range(nk)]
                 self.last_kernel_ms = dict(zip(names, [float(v) for v in ms]))
             else:
-                _lib.check(self.lib.dtfill_batch(*args))
+                _lib.check(self.lib.dtfill_batch_flags(*args, flags))
         res = {k: o[k] for k in want}
         res["status"] = o["status"]
         return res
@@ -104,7 +107,7 @@ class DtFill:
         res = self.run(xd, src_thr, val_thr, want)
         out = {k: v.cpu().numpy() for k, v in res.items()}
         if "depth" in want:
-            bad = np.nonzero(out["status"] == _lib.FRAME_INDEX_ERROR)[0]
+            bad = np.nonzero(out["status"] & _lib.FRAME_INDEX_ERROR)[0]
             if bad.size:
                 raise IndexError(
                     "frame %d: index out of bounds in depth_list[label_list-1] "

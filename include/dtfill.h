@@ -48,12 +48,20 @@ extern "C" {
 #define DTFILL_ERR_LAUNCH      -5 /* a HIP launch failed (hipGetLastError) */
 #define DTFILL_ERR_NO_DEVICE   -6 /* no usable HIP device */
 
-/* per-frame status written to frame_status[b] (device int32) */
-#define DTFILL_FRAME_OK          0
-#define DTFILL_FRAME_INDEX_ERROR 1 /* numpy would raise IndexError in depth_list[lbl-1] (tools.py:26):
-                                      a label addresses past the value list, or label 0 (no source in
-                                      the frame) with an empty value list.  out_depth of that frame is
-                                      then unspecified; out_dt / out_index are still exact. */
+/* per-frame status written to frame_status[b] (device int32): a bit set */
+#define DTFILL_FRAME_OK           0
+#define DTFILL_FRAME_INDEX_ERROR  1 /* numpy would raise IndexError in depth_list[lbl-1] (tools.py:26):
+                                       a label addresses past the value list, or label 0 (no source in
+                                       the frame) with an empty value list.  out_depth of that frame is
+                                       then unspecified; out_dt / out_index are still exact. */
+#define DTFILL_FRAME_GENERAL_PATH 2 /* informational: the frame held a pixel farther than the LDS tile
+                                       halo from every source and was computed by the full-frame
+                                       (any-distance) kernels; results are identical either way. */
+
+/* flags of dtfill_batch_flags(): path selection, for tests and benchmarks */
+#define DTFILL_FLAG_GENERAL_ONLY 1u /* skip the fused tile kernel, every frame takes the general path */
+#define DTFILL_FLAG_FUSED_ONLY   2u /* skip the general kernels: frames that need them are left
+                                       undefined and carry DTFILL_FRAME_GENERAL_PATH in their status */
 
 int dtfill_abi_version(void);
 const char *dtfill_strerror(int code);
@@ -82,16 +90,21 @@ int dtfill_batch(const float *x, int B, int H, int W, float src_thr, float val_t
                  float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
                  void *workspace, size_t ws_bytes, void *stream);
 
+/* dtfill_batch() with explicit path selection (DTFILL_FLAG_*); flags = 0 is dtfill_batch(). */
+int dtfill_batch_flags(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
+                       float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
+                       void *workspace, size_t ws_bytes, void *stream, unsigned flags);
+
 /*
  * Same pass, instrumented for bench.py: records a HIP event on `stream` before and after every
  * kernel, synchronises, and returns each kernel's duration in milliseconds in kernel_ms (HOST
- * float[dtfill_num_kernels(metric)]).  Not for production use (it blocks).
+ * float[dtfill_num_kernels(metric)]; 0 for kernels the flags skip).  Not for production use (it blocks).
  */
 int dtfill_num_kernels(int metric);
 const char *dtfill_kernel_name(int metric, int k);
 int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
                        float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
-                       void *workspace, size_t ws_bytes, void *stream, float *kernel_ms);
+                       void *workspace, size_t ws_bytes, void *stream, unsigned flags, float *kernel_ms);
 
 #ifdef __cplusplus
 }

@@ -12,23 +12,32 @@ pytestmark = pytest.mark.gpu
 CASES, DIGESTS = load_cases()
 
 
-def run(op, x, st=0.1, vt=0.1, want=("depth", "dt", "index")):
+PATHS = ("auto", "general")  # every comparison runs through the fused+fallback pass AND the general kernels alone
+
+
+def run(op, x, st=0.1, vt=0.1, want=("depth", "dt", "index"), path="auto"):
+    """One pass through the C ABI.  Returns numpy outputs; "status" keeps only the IndexError bit,
+    "general" says which frames took the any-distance kernels."""
     import torch
 
     xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to("cuda:0")
-    res = op.run(xd, st, vt, want)
+    res = op.run(xd, st, vt, want, path=path)
     torch.cuda.synchronize()
-    return {k: v.cpu().numpy() for k, v in res.items()}
+    out = {k: v.cpu().numpy() for k, v in res.items()}
+    out["general"] = (out["status"] & 2) != 0
+    out["status"] = out["status"] & 1
+    return out
 
 
-def assert_equal_to_oracle(oracle, op, x, st=0.1, vt=0.1):
+def assert_equal_to_oracle(oracle, op, x, st=0.1, vt=0.1, paths=PATHS):
     depth, dt, lbl, status = oracle.fill_batch(x, st, vt)
-    got = run(op, x, st, vt)
-    assert np.array_equal(got["dt"], dt), "distance map differs"
-    assert np.array_equal(got["index"], lbl), "label map differs: %d px" % (got["index"] != lbl).sum()
-    assert np.array_equal(got["status"], status)
-    ok = status == 0
-    assert np.array_equal(got["depth"][ok], depth[ok], equal_nan=True), "filled depth differs"
+    for path in paths:
+        got = run(op, x, st, vt, path=path)
+        assert np.array_equal(got["dt"], dt), "%s: distance map differs" % path
+        assert np.array_equal(got["index"], lbl), "%s: label map differs: %d px" % (path, (got["index"] != lbl).sum())
+        assert np.array_equal(got["status"], status), path
+        ok = status == 0
+        assert np.array_equal(got["depth"][ok], depth[ok], equal_nan=True), "%s: filled depth differs" % path
 
 
 def test_native_library_loaded(gpu_op, pkg):
@@ -39,15 +48,18 @@ def test_native_library_loaded(gpu_op, pkg):
     assert "libdtfill.so" in maps, "the HIP extension is not the code that ran"
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_golden_cases(gpu_op, name):
+def test_golden_cases(gpu_op, name, path):
     c = CASES[name]
-    got = run(gpu_op, c["x"][None], float(c["thr"][0]), float(c["thr"][1]))
+    got = run(gpu_op, c["x"][None], float(c["thr"][0]), float(c["thr"][1]), path=path)
     assert np.array_equal(got["dt"][0], c["dt"])
     assert np.array_equal(got["index"][0], c["lbl"])
     assert np.array_equal(got["status"], c["status"])
     if c["status"][0] == 0:
         assert np.array_equal(got["depth"][0], c["depth"], equal_nan=True)
+    if path == "general":
+        assert got["general"].all()
 
 
 def test_golden_cases_as_one_batch_per_shape(gpu_op):
@@ -66,14 +78,15 @@ def test_golden_cases_as_one_batch_per_shape(gpu_op):
                 assert np.array_equal(got["depth"][b], c["depth"], equal_nan=True)
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("cfg", sorted(DIGESTS))
-def test_full_size_digests(gpu_op, pkg, cfg):
+def test_full_size_digests(gpu_op, pkg, cfg, path):
     """BASELINE.json's shapes: outputs hashed against the oracle's committed sha256."""
     synth = importlib.import_module(pkg.__name__ + ".synth")
     d = DIGESTS[cfg]
     x = synth.make(cfg, B=d["B"])
     assert digest(x) == d["x"]
-    got = run(gpu_op, x)
+    got = run(gpu_op, x, path=path)
     assert digest(got["dt"]) == d["dt"]
     assert digest(got["index"]) == d["lbl"]
     assert digest(got["depth"]) == d["depth"]
@@ -178,6 +191,42 @@ def test_reference_named_functions(pkg, oracle):
         pkg.Distance_Transform(CASES["single0"]["x"], 0.1)
     with pytest.raises(TypeError):
         pkg.nearest_point(np.full((4, 4), 0.1, np.float64))
+
+
+def test_fused_kernel_alone_decides_dense_frames(gpu_op, oracle, pkg):
+    """The LDS-tile kernel by itself (general kernels skipped): on the 5 %-valid KITTI workload no
+    pixel is farther than the halo from a source, so nothing may be flagged and everything must
+    already be exact; a frame with an empty band must be flagged, and only that frame."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    x = synth.make("kitti_b32", B=4)
+    depth, dt, lbl, _ = oracle.fill_batch(x)
+    got = run(gpu_op, x, path="fused")
+    assert not got["general"].any()
+    assert np.array_equal(got["dt"], dt) and np.array_equal(got["index"], lbl) and np.array_equal(got["depth"], depth)
+    x[2, 100:160] = 0
+    got = run(gpu_op, x, path="fused")
+    assert got["general"].tolist() == [False, False, True, False]
+    for b in (0, 1, 3):
+        assert np.array_equal(got["index"][b], lbl[b]) and np.array_equal(got["depth"][b], depth[b])
+    auto = run(gpu_op, x)
+    depth2, dt2, lbl2, _ = oracle.fill_batch(x)
+    assert auto["general"].tolist() == [False, False, True, False]
+    assert np.array_equal(auto["dt"], dt2) and np.array_equal(auto["index"], lbl2) and np.array_equal(auto["depth"], depth2)
+
+
+def test_tile_seams_and_halo_boundary(gpu_op, oracle):
+    """Distances exactly at / one past the halo (16), sources on tile seams, odd frame sizes that
+    make ragged last tiles."""
+    for H, W in [(88, 152), (89, 153), (176, 304), (100, 321), (33, 40), (17, 500)]:
+        x = np.zeros((3, H, W), np.float32)
+        x[0, ::17, ::17] = 2.0   # lattice with max L1 distance 16: exactly the halo
+        x[1, ::18, ::17] = 3.0   # ... 17: one past it in places
+        x[2, H // 2, :] = 4.0    # a full row of sources: vertical distances up to H/2
+        x[2, :, W // 2] = 5.0
+        assert_equal_to_oracle(oracle, gpu_op, x)
+    rng = np.random.default_rng(8)
+    x = np.where(rng.random((2, 352, 1216)) < 0.012, rng.uniform(1, 80, (2, 352, 1216)), 0).astype(np.float32)
+    assert_equal_to_oracle(oracle, gpu_op, x)  # 1.2 %: a mix of decided and flagged frames
 
 
 def test_shape_errors(gpu_op, pkg):
