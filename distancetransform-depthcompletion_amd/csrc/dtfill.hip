@@ -93,42 +93,55 @@ __device__ __forceinline__ int ld16(const u16 *p) {
 __device__ __forceinline__ u16 st16(int v) { return (u16)(v >= INF16 ? INF16 : v); }
 
 // ------------------------------------------------------------------------------------------------
-// k_mask: one wave per image row.  Source predicate exactly as tools.py:8, mask = (1.0 - x) > thr
+// k_mask: one wave per M_RPW image rows.  Source predicate exactly as tools.py:8, mask = (1.0 - x) > thr
 // (1 = fill, 0 = source); value predicate as tools.py:22, x > thr.  Per 64-pixel word: the two bit
 // words and the row-local exclusive popcount; per row: totals (+ "masks differ" in bit 31).
 // ------------------------------------------------------------------------------------------------
+constexpr int M_RPW = 4;  // image rows per wave in k_mask (independent loads in flight)
+
 __global__ __launch_bounds__(256) void k_mask(const float *__restrict__ x, int H, int W, int Wd,
                                               float src_thr, float val_thr, u64 *__restrict__ srcbits,
                                               u64 *__restrict__ valbits, u16 *__restrict__ wpre_s,
                                               u16 *__restrict__ wpre_v, u32 *__restrict__ rowcnt_s,
                                               u32 *__restrict__ rowcnt_v) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 4 + wave, b = blockIdx.y;
-    if (i >= H) return;
-    const size_t rowid = (size_t)b * H + i;
-    const float *row = x + rowid * W;
-    u32 ps = 0, pv = 0, mis = 0;
-#pragma unroll 4
+    const int i0 = (blockIdx.x * 4 + wave) * M_RPW, b = blockIdx.y;
+    if (i0 >= H) return;
+    u32 ps[M_RPW], pv[M_RPW], mis[M_RPW];
+#pragma unroll
+    for (int q = 0; q < M_RPW; ++q) ps[q] = pv[q] = mis[q] = 0;
     for (int k = 0; k < Wd; ++k) {
         const int j = k * 64 + lane;
-        const float v = j < W ? row[j] : 0.0f;
-        const bool s = j < W && !((1.0f - v) > src_thr);
-        const bool isv = j < W && (v > val_thr);
-        const u64 sb = __ballot(s), vb = __ballot(isv);
-        if (lane == 0) {
-            const size_t wi = rowid * Wd + k;
-            srcbits[wi] = sb;
-            valbits[wi] = vb;
-            wpre_s[wi] = (u16)ps;
-            wpre_v[wi] = (u16)pv;
+        float v[M_RPW];
+#pragma unroll
+        for (int q = 0; q < M_RPW; ++q) {
+            const int i = min(i0 + q, H - 1);
+            v[q] = j < W ? x[((size_t)b * H + i) * W + j] : 0.0f;
         }
-        ps += __popcll(sb);
-        pv += __popcll(vb);
-        mis |= (sb != vb);
+#pragma unroll
+        for (int q = 0; q < M_RPW; ++q) {
+            const bool s = j < W && !((1.0f - v[q]) > src_thr);
+            const bool isv = j < W && (v[q] > val_thr);
+            const u64 sb = __ballot(s), vb = __ballot(isv);
+            if (lane == 0 && i0 + q < H) {
+                const size_t wi = ((size_t)b * H + i0 + q) * Wd + k;
+                srcbits[wi] = sb;
+                valbits[wi] = vb;
+                wpre_s[wi] = (u16)ps[q];
+                wpre_v[wi] = (u16)pv[q];
+            }
+            ps[q] += __popcll(sb);
+            pv[q] += __popcll(vb);
+            mis[q] |= (sb != vb);
+        }
     }
     if (lane == 0) {
-        rowcnt_s[rowid] = ps;
-        rowcnt_v[rowid] = pv | (mis ? 0x80000000u : 0u);
+#pragma unroll
+        for (int q = 0; q < M_RPW; ++q)
+            if (i0 + q < H) {
+                rowcnt_s[(size_t)b * H + i0 + q] = ps[q];
+                rowcnt_v[(size_t)b * H + i0 + q] = pv[q] | (mis[q] ? 0x80000000u : 0u);
+            }
     }
 }
 
@@ -265,7 +278,7 @@ constexpr int F_CAP = 100;
 // border / out-of-image value of s_x.  Must never satisfy a tap test (nv & msk) + w == d | live<<7:
 // 0x70 + w is 0x71..0x73, neither a distance < F_CAP nor 0x80 | d.  (0x7F would: 0x7F + 3 == 0x80 | 2.)
 constexpr u32 F_BORDER = 0x70;
-constexpr int F_NW = 4;   // 64-bit words a window row can touch: F_WWM/64 + 1
+constexpr int F_NW32 = 8; // 32-bit words a window row can touch: 2 * (F_WWM/64 + 1)
 constexpr int F_NT = 256; // threads per block
 constexpr int F_EB = 4;   // epilogue batch: pixels per lane walked in lockstep / gathers in flight together
 constexpr int F_RING = 4; // halo ring whose parent codes are evaluated up front with the tile's
@@ -273,29 +286,28 @@ constexpr int F_RING = 4; // halo ring whose parent codes are evaluated up front
 #define FU(r, c) ((r) * F_P + (c))
 #define FX(r, c) (((r) + 2) * F_P + (c) + 4)
 
-// 5x5 parent rule at window cell (rr, cc); returns PAR_SRC / PAR_NONE / 0x80 | tap code
-__device__ __forceinline__ int fused_parent(const u8 *__restrict__ s_x, int rr, int cc) {
-    const u8 *p = s_x + FX(rr, cc);
+// Parent step of a window cell, straight-line (no divergent control flow, so the compiler can overlap
+// the LDS reads of several cells).  p points at the cell in s_x.  The step itself is encoded,
+//   0x80 | (di+2) << 3 | (dj+2),
+// so one hop of the walk is  address += (code >> 3 & 7) * F_P + (code & 7) - (2 * F_P + 2).
+// Forward tap t has encoding ENC_F(t); the backward tap is its negation: 36 - ENC_F(t).
+#define ENC_F(t) (((TAP_DI(t) + 2) << 3) | (TAP_DJ(t) + 2))
+__device__ __forceinline__ int fused_parent(const u8 *__restrict__ p) {
     const int v = *p;
     const int d = v & 0x7F;
-    if (d == 0) return PAR_SRC;
-    if (d >= F_CAP) return PAR_NONE;
     const int live = v >> 7;
     const int sgn = live ? 1 : -1;       // backward tap = negated forward tap
     const int msk = live ? 0xFF : 0x7F;  // forward taps must be live themselves
-    const int want = d | (live ? 0x80 : 0);
-    int code = PAR_NONE;
+    int enc = -1;
 #pragma unroll
     for (int t = 7; t >= 0; --t) {  // descending: the FIRST matching tap is kept
         const int nv = p[sgn * (TAP_DI(t) * F_P + TAP_DJ(t))];
-        if ((nv & msk) + TAP_W(t) == want) code = t;
+        enc = ((nv & msk) + TAP_W(t) == v) ? ENC_F(t) : enc;
     }
-    if (code == PAR_NONE) return code;
-    // encode the step itself: 0x80 | (di+2) << 3 | (dj+2), so that a hop of the walk is
-    // address += (code >> 3 & 7) * F_P + (code & 7) - (2 * F_P + 2)
-    const int di = sgn * (int)(((TAP_DI_NIB >> (4 * code)) & 15u) - 2u);
-    const int dj = sgn * (int)(((TAP_DJ_NIB >> (4 * code)) & 15u) - 2u);
-    return 0x80 | ((di + 2) << 3) | (dj + 2);
+    enc = live ? enc : 36 - enc;
+    int code = (enc < 0 || enc > 36) ? PAR_NONE : (0x80 | enc);
+    code = d >= F_CAP ? PAR_NONE : code;
+    return d == 0 ? PAR_SRC : code;
 }
 
 __global__ __launch_bounds__(F_NT) void k_fused(
@@ -306,8 +318,8 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     int *__restrict__ frame_status, int stop_after) {
     __shared__ __attribute__((aligned(16))) u8 s_u[F_WHM * F_P];
     __shared__ __attribute__((aligned(16))) u8 s_x[(F_WHM + 4) * F_P];
-    __shared__ u64 s_sb[F_WHM * F_NW];
-    __shared__ u32 s_rk[F_WHM * F_NW];
+    __shared__ u32 s_sb[F_WHM * F_NW32];  // source bits of the window rows, 32 pixels per word
+    __shared__ u32 s_rk[F_WHM * F_NW32 / 2];  // sources before each 64-pixel word pair (frame raster order)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NWAVE = F_NT / 64;
@@ -323,52 +335,63 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     const int rh = rb - ra, cw = cb - ca;
     const int w0 = wc0 >> 6;  // first 64-bit word column the window can touch (-1 if wc0 < 0)
 
-    // ---- P0: s_x = 0x7F everywhere, s_u = CAP everywhere; fetch the window's bit words + ranks
+    // ---- P0: s_x = border everywhere, s_u = CAP everywhere; fetch the window's bit words + ranks
     {
+        u64 sbv[2];
+        u32 rkv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {  // WH * 4 <= 480 word slots: two per thread, all loads issued first
+            const int idx = tid + q * F_NT;
+            const int r = idx >> 2, k = idx & 3;
+            const int gi = wr0 + r, w = w0 + k;
+            sbv[q] = 0;
+            rkv[q] = 0;
+            if (idx < WH * 4 && gi >= 0 && gi < H && w >= 0 && w < Wd) {
+                const size_t wi = ((size_t)b * H + gi) * Wd + w;
+                sbv[q] = srcbits[wi];
+                rkv[q] = rowbase_s[(size_t)b * H + gi] + wpre_s[wi];
+            }
+        }
         u32 *x32 = reinterpret_cast<u32 *>(s_x), *u32p = reinterpret_cast<u32 *>(s_u);
         for (int k = tid; k < (F_WHM + 4) * F_P / 4; k += F_NT) x32[k] = 0x01010101u * F_BORDER;
         for (int k = tid; k < F_WHM * F_P / 4; k += F_NT) u32p[k] = 0x01010101u * F_CAP;
-#pragma unroll 4
-        for (int idx = tid; idx < WH * F_NW; idx += F_NT) {
-            const int r = idx >> 2, k = idx & 3;
-            const int gi = wr0 + r, w = w0 + k;
-            u64 sb = 0;
-            u32 rk = 0;
-            if (gi >= 0 && gi < H && w >= 0 && w < Wd) {
-                const size_t wi = ((size_t)b * H + gi) * Wd + w;
-                sb = srcbits[wi];
-                rk = rowbase_s[(size_t)b * H + gi] + wpre_s[wi];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + q * F_NT;
+            if (idx < WH * 4) {
+                const u32 lo = (u32)sbv[q], hi = (u32)(sbv[q] >> 32);
+                s_sb[2 * idx] = lo;
+                s_sb[2 * idx + 1] = hi;
+                s_rk[idx] = rkv[q];
             }
-            s_sb[idx] = sb;
-            s_rk[idx] = rk;
         }
     }
     __syncthreads();
-
     if (stop_after == 0) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
+
     // ---- P1: column scans, one lane per window column: gu -> s_u, g = min(gu, gd) -> s_x
     for (int c = ca + tid; c < cb; c += F_NT) {
         const int gj = wc0 + c;
-        const u32 *sb32 = reinterpret_cast<const u32 *>(s_sb) + ((((gj >> 6) - w0) << 1) | ((gj >> 5) & 1));
+        const u32 *sb32 = s_sb + ((gj >> 5) - 2 * w0);
         const int bit = gj & 31;
         int up = F_CAP;
 #pragma unroll 8
         for (int r = ra; r < rb; ++r) {
-            const u32 s = (sb32[r * (2 * F_NW)] >> bit) & 1u;
+            const u32 s = (sb32[r * F_NW32] >> bit) & 1u;
             up = s ? 0 : min(up + 1, F_CAP);
             s_u[FU(r, c)] = (u8)up;
         }
         int dn = F_CAP;
 #pragma unroll 8
         for (int r = rb - 1; r >= ra; --r) {
-            const u32 s = (sb32[r * (2 * F_NW)] >> bit) & 1u;
+            const u32 s = (sb32[r * F_NW32] >> bit) & 1u;
             dn = s ? 0 : min(dn + 1, F_CAP);
             s_x[FX(r, c)] = (u8)min((int)s_u[FU(r, c)], dn);
         }
     }
     __syncthreads();
-
     if (stop_after == 1) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
+
     // ---- P2: row scans, one lane per window row, four cells (one dword) per step, in place in s_x.
     // Pass 1 keeps a and the flag (dA == a); pass 2: d, liveA = flag && (a == d)  [dA >= a >= d].
     if (tid < rh) {
@@ -417,47 +440,39 @@ __global__ __launch_bounds__(F_NT) void k_fused(
         }
     }
     __syncthreads();
-
     if (stop_after == 2) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
-    // ---- P3: knight-line scan, one lane per line u = c + 2 r over columns [0, cw] (column cw is the
-    // virtual one right of the window/image edge: E = gu(.,cw-1) - 1).  Sets live where dB == d.
-    // The scan itself only loads (so the loads of unrolled steps overlap); the rows where dB == d are
-    // remembered as bits and the live flags are stored afterwards.
-    {
-        const int nU = cw + 1 + 2 * (rh - 1);
-        for (int ub = wave * 64; ub < nU; ub += F_NT) {
-            const int u = ub + lane;
-            const int u1 = min(ub + 63, nU - 1);
-            const int rlo = max(0, (ub - cw + 1) / 2), rhi = min(rh - 1, u1 / 2);
-            int D = 4 * F_CAP;
-            u64 hit0 = 0, hit1 = 0;  // bit (r2 - rlo): rows rlo..rlo+63 / rlo+64..rlo+127
-#pragma unroll 4
-            for (int r2 = rlo; r2 <= rhi; ++r2) {
-                const int c2 = u - 2 * r2;
-                const bool on = u < nU && c2 >= 0 && c2 <= cw;
-                const int rr = ra + r2;
-                const int cA = ca + min(max(c2, 0), cw - 1), cB = ca + min(max(c2 - 1, 0), cw - 1);
-                const int eA = s_u[FU(rr, cA)], eB = s_u[FU(rr, cB)], v = s_x[FX(rr, cA)];
+
+    // ---- P3: knight-line scan over columns [0, cw] (column cw is the virtual one right of the
+    // window/image edge: E = gu(.,cw-1) - 1).  Lane u sits at column (u - 2 r) mod (cw+1) in row r: a
+    // lane whose line leaves the window on the left re-enters on the right as a NEW line (D reset), so
+    // exactly cw+1 lanes are busy in every row.
+    if (tid <= cw) {
+        const int n = cw + 1;
+        int c2 = tid;
+        int D = 4 * F_CAP;
+        for (int rbase = 0; rbase < rh; rbase += 4) {  // 4 rows per batch: 12 loads, 4 steps, <= 4 stores
+            int eA[4], eB[4], v[4], cc2[4], xi[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = ra + min(rbase + q, rh - 1);
+                cc2[q] = c2;
+                xi[q] = FX(rr, ca + min(c2, cw - 1));
+                eA[q] = s_u[FU(rr, ca + min(c2, cw - 1))];
+                eB[q] = s_u[FU(rr, ca + max(c2 - 1, 0))];
+                v[q] = s_x[xi[q]];
+                c2 -= 2;
+                c2 += c2 < 0 ? n : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = cc2[q];
                 const int dbv = D + 3;
-                int e = (on && c2 < cw) ? eA : 4 * F_CAP;
-                if (on && c2 >= 1) e = min(e, eB - 1);
-                const bool hit = on && c2 < cw && v == dbv && dbv < F_CAP;  // v == dbv: v has no live bit
-                const int k = r2 - rlo;
-                if (k < 64)
-                    hit0 |= (u64)hit << k;
-                else
-                    hit1 |= (u64)hit << (k - 64);
-                D = on ? min(min(e, dbv), 4 * F_CAP) : 4 * F_CAP;
-            }
-            while (hit0) {
-                const int k = __ffsll((long long)hit0) - 1;
-                hit0 &= hit0 - 1;
-                s_x[FX(ra + rlo + k, ca + u - 2 * (rlo + k))] |= 0x80;
-            }
-            while (hit1) {
-                const int k = 64 + __ffsll((long long)hit1) - 1;
-                hit1 &= hit1 - 1;
-                s_x[FX(ra + rlo + k, ca + u - 2 * (rlo + k))] |= 0x80;
+                int e = c < cw ? eA[q] : 4 * F_CAP;
+                e = c >= 1 ? min(e, eB[q] - 1) : e;
+                // v == dbv: the byte has no live bit yet and dB equals d
+                if (rbase + q < rh && c < cw && v[q] == dbv && dbv < F_CAP) s_x[xi[q]] = (u8)(v[q] | 0x80);
+                D = min(min(e, dbv), 4 * F_CAP);
+                D = c < 2 ? 4 * F_CAP : D;  // the lane wraps after this row: it starts a new line at the right edge
             }
         }
     }
@@ -473,7 +488,7 @@ __global__ __launch_bounds__(F_NT) void k_fused(
         const int pc0 = max(ca, FR - F_RING), pc1 = min(cb, FR + tw + F_RING);
         for (int cc = pc0 + lane; cc < pc1; cc += 64) {
 #pragma unroll 4
-            for (int rr = pr0 + wave; rr < pr1; rr += NWAVE) s_par[FU(rr, cc)] = (u8)fused_parent(s_x, rr, cc);
+            for (int rr = pr0 + wave; rr < pr1; rr += NWAVE) s_par[FU(rr, cc)] = (u8)fused_parent(s_x + FX(rr, cc));
         }
     }
     __syncthreads();
@@ -498,28 +513,42 @@ __global__ __launch_bounds__(F_NT) void k_fused(
                 const int d = s_x[FX(rr, cc)] & 0x7F;
                 dd[e] = d;
                 ok[e] = tr < th && d <= FR;
-                if (tr < th && d > FR) overflow = true;  // undecidable here: the frame takes the general path
+                overflow |= tr < th && d > FR;  // undecidable here: the frame takes the general path
                 pos[e] = FU(rr, cc);
                 code[e] = ok[e] ? (int)s_par[FU(rr, cc)] : PAR_NONE;
             }
-            for (int hop = 0; hop <= FR; ++hop) {
-                bool moving = false;
+            for (int guard = 0; guard <= 2 * FR; ++guard) {
+                // straight-line hops while any lane is on an evaluated, non-terminal cell
+                for (int hop = 0; hop <= FR; ++hop) {
+                    bool moving = false;
+#pragma unroll
+                    for (int e = 0; e < F_EB; ++e) {
+                        const int c = code[e];
+                        const bool mv = c >= 0x80 && c < PAR_NONE;
+                        pos[e] += mv ? ((c >> 3) & 7) * F_P + (c & 7) - (2 * F_P + 2) : 0;
+                        code[e] = s_par[pos[e]];
+                        moving |= mv;
+                    }
+                    if (!__any(moving)) break;
+                }
+                // rare: a walker stands on a halo cell nobody has evaluated yet
 #pragma unroll
                 for (int e = 0; e < F_EB; ++e) {
-                    int c = code[e];
-                    if (c < 0x80) {  // halo cell nobody has evaluated yet
+                    if (code[e] < 0x80) {
                         const int r_ = pos[e] / F_P;
-                        c = fused_parent(s_x, r_, pos[e] - r_ * F_P);
+                        const int c = fused_parent(s_x + FX(r_, pos[e] - r_ * F_P));
                         s_par[pos[e]] = (u8)c;  // same value from every writer
+                        code[e] = c;
                     }
-                    if (c < PAR_NONE) {
-                        pos[e] += ((c >> 3) & 7) * F_P + (c & 7) - (2 * F_P + 2);
-                        c = s_par[pos[e]];
-                        moving = true;
-                    }
-                    code[e] = c;
                 }
-                if (!__any(moving)) break;
+                // done only when every walker stands on a terminal cell.  (Not "nobody moved and nobody
+                // was stuck": another wave may have just written the code of a cell a stalled walker
+                // stands on, and the re-read above has then picked up a tap code in an iteration that
+                // did not move.)
+                bool pending = false;
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) pending |= code[e] < PAR_NONE;
+                if (!__any(pending)) break;
             }
             if (stop_after == 5) {  // timing only: keep the walk alive, skip the rest
 #pragma unroll
@@ -535,8 +564,10 @@ __global__ __launch_bounds__(F_NT) void k_fused(
                 const int pr_ = pos[e] / F_P, pc_ = pos[e] - pr_ * F_P;
                 const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
                 const int gj = wc0 + c_;
-                const int k = (gj >> 6) - w0;
-                lab[e] = source_rank(s_rk[r_ * F_NW + k], s_sb[r_ * F_NW + k], gj);
+                const int k = r_ * (F_NW32 / 2) + (gj >> 6) - w0;
+                const u32 lo = s_sb[2 * k], hi = s_sb[2 * k + 1];
+                const u32 below = (1u << (gj & 31)) - 1u;
+                lab[e] = (int)s_rk[k] + ((gj & 32) ? __popc(lo) + __popc(hi & below) : __popc(lo & below)) + 1;
                 spx[e] = (wr0 + r_) * W + gj;
             }
             if (stop_after == 6) {
@@ -858,7 +889,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         if (ev) (void)hipEventRecord(ev[k++], st);
     };
     mark();
-    k_mask<<<dim3((H + 3) / 4, B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits,
+    k_mask<<<dim3((H + 4 * M_RPW - 1) / (4 * M_RPW), B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits,
                                                 c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s,
