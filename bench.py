@@ -128,6 +128,13 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         acc = {k: v for k, v in acc.items() if v > 0}
         dom = max(acc, key=acc.get)
+        traffic = None
+        try:  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj.get("kernel") == dom and tj.get("workload") == args.workload and B == 32:
+                traffic = tj["fetch_bytes_corrected"] + tj["write_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
         algo_bytes = BYTES_PER_PIXEL * B * H * W
         achieved = algo_bytes / (acc[dom] * 1e-3) / 1e9
         line = {
@@ -150,7 +157,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes": algo_bytes,
                 "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
                 "pass_achieved_GBs": round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                 "pass_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
