@@ -257,57 +257,75 @@ __device__ __forceinline__ float gather_depth(const float *__restrict__ xf, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_fused: one workgroup per window = tile (<= F_THM x F_TWM) + halo FR, everything in LDS.
-//   s_u : uint8 gu (column scan from above, capped at F_CAP); after the knight-line scan the same
-//         bytes hold parent codes (bit 7 set marks "this byte is a code", so no refill pass)
-//   s_x : uint8 g -> a|flag -> d|live<<7, rewritten in place by the row scans; rows/columns outside
-//         the image and a border (2 rows top/bottom, 4 columns left, next row's border on the right)
-//         stay F_BORDER = "never matches a tap"
-// In-place row scans: left-to-right a(c) = min(g(c), a(c-1)+1); right-to-left over a itself,
-// d(c) = min(a(c), d(c+1)+1), which equals min over g on both sides because a <= g and a(k)+(k-c) is
-// the length of a real path.  So g is dead after the first pass and two window arrays suffice.
-// LDS row pitch 196 B = 49 dwords (odd): lanes walking 64 different ROWS at one column hit distinct
-// banks; lanes on consecutive COLUMNS share dwords.  53.6 KB per block -> 3 blocks per CU.
+// k_fused: one workgroup (2 waves) per window = tile (<= 96 x 160) + halo FR, bit-sliced.
+//
+// Lane r owns window row r as six 32-bit words per bit plane (bit c%32 of word c/32 = window column c).
+// Level-synchronous form of the identity in the file header (checked in
+// tests/parallel_model.py): with E_t = {d == t} and L_t = live pixels of E_t (E_0 = L_0 = sources),
+//   E_t = dilate4(D_{t-1}) & ~D_{t-1} & in-image
+//   forward tap T = (di,dj,w) offers   shift(L_{t-w}, di, dj)   to the pixels of E_t; L_t = those offered any
+//   backward tap (negated offset)      shift(E_{t-w}, -di, -dj) to E_t \ L_t
+//   the FIRST tap in cv2 order wins (taken-mask chain); the winning step is recorded in six "code planes"
+//   holding the bits of enc = (di+2)<<3 | (dj+2)  (sources: enc 18 = step (0,0)).
+// A horizontal shift of a row is one v_alignbit per word; rows r-2..r+2 of the previous three levels
+// come from a 4-slot LDS ring (one barrier per level).  Levels stop at FR or when a level is empty.
+// Then every lane un-slices its row, 4 pixels per step, into the byte array s_par (0x80 | enc; 0x80
+// itself = undecided), which reuses the ring's memory, and the tile pixels walk to their sources in
+// lock-step; d is |drow| + |dcol| to the root.
+// LDS: 25.3 KB ring/s_par + 6 KB bit words and ranks.
 // ------------------------------------------------------------------------------------------------
 constexpr int FR = 16;
-constexpr int F_THM = 88, F_TWM = 160;
-constexpr int F_WHM = F_THM + 2 * FR;  // 120
-constexpr int F_WWM = F_TWM + 2 * FR;  // 192
-constexpr int F_P = 196;
-constexpr int F_CAP = 100;
-// border / out-of-image value of s_x.  Must never satisfy a tap test (nv & msk) + w == d | live<<7:
-// 0x70 + w is 0x71..0x73, neither a distance < F_CAP nor 0x80 | d.  (0x7F would: 0x7F + 3 == 0x80 | 2.)
-constexpr u32 F_BORDER = 0x70;
-constexpr int F_NW32 = 8; // 32-bit words a window row can touch: 2 * (F_WWM/64 + 1)
-constexpr int F_NT = 256; // threads per block
-constexpr int F_EB = 4;   // epilogue batch: pixels per lane walked in lockstep / gathers in flight together
-constexpr int F_RING = 4; // halo ring whose parent codes are evaluated up front with the tile's
+constexpr int F_THM = 96, F_TWM = 160;
+constexpr int F_WHM = F_THM + 2 * FR;  // 128 rows = lanes of two waves
+constexpr int F_WWM = F_TWM + 2 * FR;  // 192 columns = 6 words
+constexpr int F_NT = 128;
+constexpr int F_P = 196;               // s_par row pitch: 49 dwords (odd) -> lane-per-row dword stores are conflict-free
+constexpr int F_NWD = 6;               // 32-bit words per window row
+constexpr int F_RROWS = F_WHM + 4;     // ring rows: 2 zero rows above and below the window
+constexpr int F_EB = 8;                // tile pixels per lane walked in lock-step
+// byte code of a source: 0x80 | 18 = step (0,0)
+constexpr int F_NONE = 0xC0 | 18;      // byte code of an undecided pixel: also step (0,0), plus bit 6
+static_assert(F_WWM == 32 * F_NWD, "window width must be six words");
+static_assert(4 * 2 * F_RROWS * F_NWD * 4 >= F_WHM * F_P, "s_par must fit in the ring's memory");
 
-#define FU(r, c) ((r) * F_P + (c))
-#define FX(r, c) (((r) + 2) * F_P + (c) + 4)
-
-// Parent step of a window cell, straight-line (no divergent control flow, so the compiler can overlap
-// the LDS reads of several cells).  p points at the cell in s_x.  The step itself is encoded,
-//   0x80 | (di+2) << 3 | (dj+2),
-// so one hop of the walk is  address += (code >> 3 & 7) * F_P + (code & 7) - (2 * F_P + 2).
-// Forward tap t has encoding ENC_F(t); the backward tap is its negation: 36 - ENC_F(t).
 #define ENC_F(t) (((TAP_DI(t) + 2) << 3) | (TAP_DJ(t) + 2))
-__device__ __forceinline__ int fused_parent(const u8 *__restrict__ p) {
-    const int v = *p;
-    const int d = v & 0x7F;
-    const int live = v >> 7;
-    const int sgn = live ? 1 : -1;       // backward tap = negated forward tap
-    const int msk = live ? 0xFF : 0x7F;  // forward taps must be live themselves
-    int enc = -1;
+
+// word i of the row shifted so that result[c] = row[c + DJ]
+template <int DJ>
+__device__ __forceinline__ u32 hshift(const u32 (&w)[F_NWD], int i) {
+    const u32 lo = i > 0 ? w[i - 1] : 0u, me = w[i], hi = i < F_NWD - 1 ? w[i + 1] : 0u;
+    if (DJ == 0) return me;
+    if (DJ > 0) return __builtin_amdgcn_alignbit(hi, me, DJ);
+    return __builtin_amdgcn_alignbit(me, lo, 32 + DJ);
+}
+
+// one tap of the first-match chain: cand = shift(src, DJ); winners get the bits of ENC in the code planes
+template <int DJ, int ENC>
+__device__ __forceinline__ void tap_step(const u32 (&src)[F_NWD], u32 (&taken)[F_NWD], u32 (&C)[6][F_NWD]) {
 #pragma unroll
-    for (int t = 7; t >= 0; --t) {  // descending: the FIRST matching tap is kept
-        const int nv = p[sgn * (TAP_DI(t) * F_P + TAP_DJ(t))];
-        enc = ((nv & msk) + TAP_W(t) == v) ? ENC_F(t) : enc;
+    for (int i = 0; i < F_NWD; ++i) {
+        const u32 cand = hshift<DJ>(src, i);
+        const u32 sel = cand & ~taken[i];
+        taken[i] |= cand;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (ENC & (1 << j)) C[j][i] |= sel;
     }
-    enc = live ? enc : 36 - enc;
-    int code = (enc < 0 || enc > 36) ? PAR_NONE : (0x80 | enc);
-    code = d >= F_CAP ? PAR_NONE : code;
-    return d == 0 ? PAR_SRC : code;
+}
+
+__device__ __forceinline__ void ring_load(const u32 *__restrict__ ring, int slot, int plane, int row, u32 (&w)[F_NWD]) {
+    const uint2 *p = reinterpret_cast<const uint2 *>(ring + ((slot * 2 + plane) * F_RROWS + row) * F_NWD);
+#pragma unroll
+    for (int i = 0; i < F_NWD / 2; ++i) {
+        const uint2 v = p[i];
+        w[2 * i] = v.x;
+        w[2 * i + 1] = v.y;
+    }
+}
+__device__ __forceinline__ void ring_store(u32 *__restrict__ ring, int slot, int plane, int row, const u32 (&w)[F_NWD]) {
+    uint2 *p = reinterpret_cast<uint2 *>(ring + ((slot * 2 + plane) * F_RROWS + row) * F_NWD);
+#pragma unroll
+    for (int i = 0; i < F_NWD / 2; ++i) p[i] = make_uint2(w[2 * i], w[2 * i + 1]);
 }
 
 __global__ __launch_bounds__(F_NT) void k_fused(
@@ -316,10 +334,9 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
     float *__restrict__ out_dt, int32_t *__restrict__ out_index, int *__restrict__ fflag,
     int *__restrict__ frame_status, int stop_after) {
-    __shared__ __attribute__((aligned(16))) u8 s_u[F_WHM * F_P];
-    __shared__ __attribute__((aligned(16))) u8 s_x[(F_WHM + 4) * F_P];
-    __shared__ u32 s_sb[F_WHM * F_NW32];  // source bits of the window rows, 32 pixels per word
-    __shared__ u32 s_rk[F_WHM * F_NW32 / 2];  // sources before each 64-pixel word pair (frame raster order)
+    __shared__ __attribute__((aligned(16))) u32 s_ring[4 * 2 * F_RROWS * F_NWD];  // later: s_par bytes
+    __shared__ u32 s_sb[F_WHM * 8];  // source bits of the window rows, image-aligned 64-pixel words (as u32 pairs)
+    __shared__ u32 s_rk[F_WHM * 4];  // sources before each of those 64-pixel words (frame raster order)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NWAVE = F_NT / 64;
@@ -329,173 +346,162 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     const int th = min(TH, H - r0), tw = min(TW, W - c0);
     const int wr0 = r0 - FR, wc0 = c0 - FR;  // image coords of window cell (0,0)
     const int WH = th + 2 * FR, WW = tw + 2 * FR;
-    // in-image part of the window, window coords
-    const int ra = max(0, -wr0), rb = min(WH, H - wr0);
-    const int ca = max(0, -wc0), cb = min(WW, W - wc0);
-    const int rh = rb - ra, cw = cb - ca;
-    const int w0 = wc0 >> 6;  // first 64-bit word column the window can touch (-1 if wc0 < 0)
+    const int ca = max(0, -wc0), cb = min(WW, W - wc0);  // in-image window columns [ca, cb)
+    const int ra = max(0, -wr0), rb = min(WH, H - wr0);  // in-image window rows
+    const int w0 = wc0 >> 6;                             // first image word column the window touches (-1 if wc0 < 0)
+    const int sh = wc0 - 64 * w0;                        // window column 0 is bit sh of image word w0
 
-    // ---- P0: s_x = border everywhere, s_u = CAP everywhere; fetch the window's bit words + ranks
+    // ---- P0: this lane's row: image-aligned words -> LDS (for the ranks), window-aligned planes -> registers
+    const int r = tid;  // window row of this lane
+    u32 M[F_NWD], D[F_NWD];
     {
-        u64 sbv[2];
-        u32 rkv[2];
+        const int gi = wr0 + r;
+        const bool rowin = r < WH && gi >= 0 && gi < H;
+        u32 g[10];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {  // WH * 4 <= 480 word slots: two per thread, all loads issued first
-            const int idx = tid + q * F_NT;
-            const int r = idx >> 2, k = idx & 3;
-            const int gi = wr0 + r, w = w0 + k;
-            sbv[q] = 0;
-            rkv[q] = 0;
-            if (idx < WH * 4 && gi >= 0 && gi < H && w >= 0 && w < Wd) {
+        for (int k = 0; k < 4; ++k) {
+            const int w = w0 + k;
+            u64 sb = 0;
+            u32 rk = 0;
+            if (rowin && w >= 0 && w < Wd) {
                 const size_t wi = ((size_t)b * H + gi) * Wd + w;
-                sbv[q] = srcbits[wi];
-                rkv[q] = rowbase_s[(size_t)b * H + gi] + wpre_s[wi];
+                sb = srcbits[wi];
+                rk = rowbase_s[(size_t)b * H + gi] + wpre_s[wi];
             }
+            g[2 * k] = (u32)sb;
+            g[2 * k + 1] = (u32)(sb >> 32);
+            s_sb[r * 8 + 2 * k] = g[2 * k];
+            s_sb[r * 8 + 2 * k + 1] = g[2 * k + 1];
+            s_rk[r * 4 + k] = rk;
         }
-        u32 *x32 = reinterpret_cast<u32 *>(s_x), *u32p = reinterpret_cast<u32 *>(s_u);
-        for (int k = tid; k < (F_WHM + 4) * F_P / 4; k += F_NT) x32[k] = 0x01010101u * F_BORDER;
-        for (int k = tid; k < F_WHM * F_P / 4; k += F_NT) u32p[k] = 0x01010101u * F_CAP;
+        g[8] = g[9] = 0;
+        const bool hi = sh & 32;  // block-uniform
+        const int s5 = sh & 31;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int idx = tid + q * F_NT;
-            if (idx < WH * 4) {
-                const u32 lo = (u32)sbv[q], hi = (u32)(sbv[q] >> 32);
-                s_sb[2 * idx] = lo;
-                s_sb[2 * idx + 1] = hi;
-                s_rk[idx] = rkv[q];
-            }
+        for (int i = 0; i < F_NWD; ++i) {
+            const u32 lo_w = hi ? g[i + 1] : g[i], hi_w = hi ? g[i + 2] : g[i + 1];
+            const u32 word = s5 ? __builtin_amdgcn_alignbit(hi_w, lo_w, s5) : lo_w;
+            // in-image columns of this word: [max(ca, 32 i), min(cb, 32 i + 32))
+            const int lo = max(ca - 32 * i, 0), up = min(cb - 32 * i, 32);
+            u32 m = 0;
+            if (rowin && up > lo) m = (up >= 32 ? 0xFFFFFFFFu : ((1u << up) - 1u)) & ~((1u << lo) - 1u);
+            M[i] = m;
+            D[i] = word & m;
         }
+    }
+    // level 0: E_0 = L_0 = sources; zero the rest of the ring (levels "-1,-2,-3" and the guard rows)
+    for (int k = tid; k < 4 * 2 * F_RROWS * F_NWD; k += F_NT) s_ring[k] = 0;
+    __syncthreads();
+    ring_store(s_ring, 0, 0, r + 2, D);
+    ring_store(s_ring, 0, 1, r + 2, D);
+    u32 C[6][F_NWD];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int i = 0; i < F_NWD; ++i) C[j][i] = ((18 >> j) & 1) ? D[i] : 0u;  // sources: enc 18
+    u32 Dup[F_NWD], Ddn[F_NWD], Eprev[F_NWD], Lprev[F_NWD];
+#pragma unroll
+    for (int i = 0; i < F_NWD; ++i) {
+        Dup[i] = Ddn[i] = 0;
+        Eprev[i] = Lprev[i] = D[i];
     }
     __syncthreads();
     if (stop_after == 0) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
-    // ---- P1: column scans, one lane per window column: gu -> s_u, g = min(gu, gd) -> s_x
-    for (int c = ca + tid; c < cb; c += F_NT) {
-        const int gj = wc0 + c;
-        const u32 *sb32 = s_sb + ((gj >> 5) - 2 * w0);
-        const int bit = gj & 31;
-        int up = F_CAP;
-#pragma unroll 8
-        for (int r = ra; r < rb; ++r) {
-            const u32 s = (sb32[r * F_NW32] >> bit) & 1u;
-            up = s ? 0 : min(up + 1, F_CAP);
-            s_u[FU(r, c)] = (u8)up;
+    // ---- P1: levels
+    for (int t = 1; t <= FR; ++t) {
+        const int s1 = (t - 1) & 3, s2 = (t - 2) & 3, s3 = (t - 3) & 3, sw = t & 3;
+        u32 nb[F_NWD], taken[F_NWD], Et[F_NWD], Lt[F_NWD];
+        // dilation of D_{t-1}: left/right in registers, up/down through the rows r-1 / r+1 of E_{t-1}
+        ring_load(s_ring, s1, 0, r + 1, nb);
+#pragma unroll
+        for (int i = 0; i < F_NWD; ++i) Dup[i] |= nb[i];
+        u32 E1d[F_NWD];
+        ring_load(s_ring, s1, 0, r + 3, E1d);
+        bool nonempty = false;
+#pragma unroll
+        for (int i = 0; i < F_NWD; ++i) {
+            Ddn[i] |= E1d[i];
+            const u32 dil = hshift<1>(D, i) | hshift<-1>(D, i) | Dup[i] | Ddn[i];
+            Et[i] = dil & ~D[i] & M[i];
+            taken[i] = ~Et[i];
+            nonempty |= Et[i] != 0;
         }
-        int dn = F_CAP;
-#pragma unroll 8
-        for (int r = rb - 1; r >= ra; --r) {
-            const u32 s = (sb32[r * F_NW32] >> bit) & 1u;
-            dn = s ? 0 : min(dn + 1, F_CAP);
-            s_x[FX(r, c)] = (u8)min((int)s_u[FU(r, c)], dn);
+        // forward taps in cv2 order; the candidates are live pixels of levels t-3, t-2, t-1
+        ring_load(s_ring, s3, 1, r + 0, nb);  // L_{t-3}, row r-2
+        tap_step<-1, ENC_F(0)>(nb, taken, C);
+        tap_step<1, ENC_F(1)>(nb, taken, C);
+        {
+            u32 l3[F_NWD], l2[F_NWD], l1[F_NWD];
+            ring_load(s_ring, s3, 1, r + 1, l3);  // L_{t-3}, row r-1
+            ring_load(s_ring, s2, 1, r + 1, l2);  // L_{t-2}, row r-1
+            ring_load(s_ring, s1, 1, r + 1, l1);  // L_{t-1}, row r-1
+            tap_step<-2, ENC_F(2)>(l3, taken, C);
+            tap_step<-1, ENC_F(3)>(l2, taken, C);
+            tap_step<0, ENC_F(4)>(l1, taken, C);
+            tap_step<1, ENC_F(5)>(l2, taken, C);
+            tap_step<2, ENC_F(6)>(l3, taken, C);
         }
+        tap_step<-1, ENC_F(7)>(Lprev, taken, C);
+#pragma unroll
+        for (int i = 0; i < F_NWD; ++i) {
+            Lt[i] = taken[i] & Et[i];
+            taken[i] = ~(Et[i] & ~Lt[i]);  // backward chain only for the non-live pixels of E_t
+        }
+        // backward taps (negated offsets, same order); candidates are ALL pixels of levels t-3, t-2, t-1
+        ring_load(s_ring, s3, 0, r + 4, nb);  // E_{t-3}, row r+2
+        tap_step<1, 36 - ENC_F(0)>(nb, taken, C);
+        tap_step<-1, 36 - ENC_F(1)>(nb, taken, C);
+        {
+            u32 e3[F_NWD], e2[F_NWD];
+            ring_load(s_ring, s3, 0, r + 3, e3);  // E_{t-3}, row r+1
+            ring_load(s_ring, s2, 0, r + 3, e2);  // E_{t-2}, row r+1
+            tap_step<2, 36 - ENC_F(2)>(e3, taken, C);
+            tap_step<1, 36 - ENC_F(3)>(e2, taken, C);
+            tap_step<0, 36 - ENC_F(4)>(E1d, taken, C);
+            tap_step<-1, 36 - ENC_F(5)>(e2, taken, C);
+            tap_step<-2, 36 - ENC_F(6)>(e3, taken, C);
+        }
+        tap_step<1, 36 - ENC_F(7)>(Eprev, taken, C);
+#pragma unroll
+        for (int i = 0; i < F_NWD; ++i) {
+            D[i] |= Et[i];
+            Eprev[i] = Et[i];
+            Lprev[i] = Lt[i];
+        }
+        ring_store(s_ring, sw, 0, r + 2, Et);
+        ring_store(s_ring, sw, 1, r + 2, Lt);
+        if (!__syncthreads_or(nonempty)) break;  // nothing at distance t anywhere: nothing farther either
     }
-    __syncthreads();
     if (stop_after == 1) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
-    // ---- P2: row scans, one lane per window row, four cells (one dword) per step, in place in s_x.
-    // Pass 1 keeps a and the flag (dA == a); pass 2: d, liveA = flag && (a == d)  [dA >= a >= d].
-    if (tid < rh) {
-        const int r = ra + tid;
-        u32 *xr = reinterpret_cast<u32 *>(s_x + FX(r, 0));
-        const u32 *ur = reinterpret_cast<const u32 *>(s_u + FU(r, 0));
-        const int k0 = ca >> 2, k1 = (cb + 3) >> 2;
-        int a = F_CAP, dA = F_CAP;
-#pragma unroll 2
-        for (int k = k0; k < k1; ++k) {
-            const u32 g4 = xr[k], u4 = ur[k];
-            u32 out = 0;
+    // ---- P2: un-slice the code planes of this row into bytes, 4 pixels per step.
+    // ((nibble * 0x00204081) & 0x01010101) spreads bits 0..3 of the nibble to the low bits of 4 bytes.
+    u8 *s_par = reinterpret_cast<u8 *>(s_ring);
+    __syncthreads();  // the ring is dead for everybody before its memory becomes s_par
+    {
+        u32 *prow = reinterpret_cast<u32 *>(s_par + r * F_P);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int g = (g4 >> (8 * t)) & 0xFF, u = (u4 >> (8 * t)) & 0xFF;
-                a = min(g, a + 1);
-                dA = min(u, dA + 1);
-                out |= (u32)(a | (dA == a ? 0x80 : 0)) << (8 * t);
-            }
-            // cells of an edge dword that lie outside the image keep F_BORDER
-            const int cl = 4 * k;
-            u32 keep = 0xFFFFFFFFu;
-            if (cl < ca) keep &= 0xFFFFFFFFu << (8 * (ca - cl));
-            if (cl + 4 > cb) keep &= 0xFFFFFFFFu >> (8 * (cl + 4 - cb));
-            xr[k] = (out & keep) | ((0x01010101u * F_BORDER) & ~keep);
-        }
-        int d = F_CAP;
-#pragma unroll 2
-        for (int k = k1 - 1; k >= k0; --k) {
-            const u32 v4 = xr[k];
-            u32 out = 0;
+        for (int i = 0; i < F_NWD; ++i) {
 #pragma unroll
-            for (int t = 3; t >= 0; --t) {
-                const int v = (v4 >> (8 * t)) & 0xFF;
-                const int av = v & 0x7F;
-                const int dn = d + 1;
-                d = min(av, dn);
-                const int live = (v >> 7) & (av <= dn) & (d < F_CAP);
-                out |= (u32)(d | (live << 7)) << (8 * t);
+            for (int q = 0; q < 8; ++q) {
+                u32 v = 0x80808080u;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const u32 nib = (C[j][i] >> (4 * q)) & 0xFu;
+                    v |= ((nib * 0x00204081u) & 0x01010101u) << j;
+                }
+                // undecided pixels (not in D): no plane bit is set; give them F_NONE = 0x80 | 0x52
+                const u32 und = ((~D[i] >> (4 * q)) & 0xFu) * 0x00204081u & 0x01010101u;
+                prow[i * 8 + q] = v | und * 0x52u;
             }
-            const int cl = 4 * k;
-            u32 keep = 0xFFFFFFFFu;
-            if (cl < ca) keep &= 0xFFFFFFFFu << (8 * (ca - cl));
-            if (cl + 4 > cb) keep &= 0xFFFFFFFFu >> (8 * (cl + 4 - cb));
-            xr[k] = (out & keep) | ((0x01010101u * F_BORDER) & ~keep);
         }
     }
     __syncthreads();
     if (stop_after == 2) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
-    // ---- P3: knight-line scan over columns [0, cw] (column cw is the virtual one right of the
-    // window/image edge: E = gu(.,cw-1) - 1).  Lane u sits at column (u - 2 r) mod (cw+1) in row r: a
-    // lane whose line leaves the window on the left re-enters on the right as a NEW line (D reset), so
-    // exactly cw+1 lanes are busy in every row.
-    if (tid <= cw) {
-        const int n = cw + 1;
-        int c2 = tid;
-        int D = 4 * F_CAP;
-        for (int rbase = 0; rbase < rh; rbase += 4) {  // 4 rows per batch: 12 loads, 4 steps, <= 4 stores
-            int eA[4], eB[4], v[4], cc2[4], xi[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rr = ra + min(rbase + q, rh - 1);
-                cc2[q] = c2;
-                xi[q] = FX(rr, ca + min(c2, cw - 1));
-                eA[q] = s_u[FU(rr, ca + min(c2, cw - 1))];
-                eB[q] = s_u[FU(rr, ca + max(c2 - 1, 0))];
-                v[q] = s_x[xi[q]];
-                c2 -= 2;
-                c2 += c2 < 0 ? n : 0;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = cc2[q];
-                const int dbv = D + 3;
-                int e = c < cw ? eA[q] : 4 * F_CAP;
-                e = c >= 1 ? min(e, eB[q] - 1) : e;
-                // v == dbv: the byte has no live bit yet and dB equals d
-                if (rbase + q < rh && c < cw && v[q] == dbv && dbv < F_CAP) s_x[xi[q]] = (u8)(v[q] | 0x80);
-                D = min(min(e, dbv), 4 * F_CAP);
-                D = c < 2 ? 4 * F_CAP : D;  // the lane wraps after this row: it starts a new line at the right edge
-            }
-        }
-    }
-    __syncthreads();
-    if (stop_after == 3) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
-
-    // ---- P4: parent codes of the tile cells and a ring of F_RING halo cells around them (gu is dead:
-    // the codes overwrite it; a byte < 0x80 is a leftover gu value = "not evaluated yet", which the
-    // rest of the halo stays until a chain reaches it)
-    u8 *s_par = s_u;
-    {
-        const int pr0 = max(ra, FR - F_RING), pr1 = min(rb, FR + th + F_RING);
-        const int pc0 = max(ca, FR - F_RING), pc1 = min(cb, FR + tw + F_RING);
-        for (int cc = pc0 + lane; cc < pc1; cc += 64) {
-#pragma unroll 4
-            for (int rr = pr0 + wave; rr < pr1; rr += NWAVE) s_par[FU(rr, cc)] = (u8)fused_parent(s_x + FX(rr, cc));
-        }
-    }
-    __syncthreads();
-    if (stop_after == 4) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
-
-    // ---- P5: tile pixels: walk to the source, rank -> label, gather, store.  Each lane walks F_EB
-    // pixels in lockstep (their LDS reads are independent, so the hop latencies overlap) and then has
+    // ---- P3: tile pixels: walk to the source, d, rank -> label, gather, store.  Each lane walks F_EB
+    // pixels in lock-step (their LDS reads are independent, so the hop latencies overlap) and then has
     // F_EB global gathers in flight together.
     const size_t fo = (size_t)b * H * W;
     const int nval = finfo[b * FI_STRIDE + FI_NVAL];
@@ -504,86 +510,72 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     for (int tc = lane; tc < tw; tc += 64) {
         const int cc = FR + tc;
         for (int trb = wave; trb < th; trb += NWAVE * F_EB) {
-            int pos[F_EB], code[F_EB], dd[F_EB];  // pos = FU(row, col): linear LDS index of the walker
+            int pos[F_EB], code[F_EB];  // pos = row * F_P + col: byte index of the walker in s_par
             bool ok[F_EB];
 #pragma unroll
             for (int e = 0; e < F_EB; ++e) {
                 const int tr = trb + e * NWAVE;
-                const int rr = FR + min(tr, th - 1);
-                const int d = s_x[FX(rr, cc)] & 0x7F;
-                dd[e] = d;
-                ok[e] = tr < th && d <= FR;
-                overflow |= tr < th && d > FR;  // undecidable here: the frame takes the general path
-                pos[e] = FU(rr, cc);
-                code[e] = ok[e] ? (int)s_par[FU(rr, cc)] : PAR_NONE;
+                pos[e] = (FR + min(tr, th - 1)) * F_P + cc;
+                code[e] = s_par[pos[e]];
+                ok[e] = tr < th && code[e] != F_NONE;
+                overflow |= tr < th && code[e] == F_NONE;  // undecidable here: the frame takes the general path
             }
-            for (int guard = 0; guard <= 2 * FR; ++guard) {
-                // straight-line hops while any lane is on an evaluated, non-terminal cell
-                for (int hop = 0; hop <= FR; ++hop) {
-                    bool moving = false;
+            // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
+            // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
+            // overlap.  Two hops between "everybody arrived?" checks.
+            for (int hop = 0; hop < FR; hop += 2) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
                     for (int e = 0; e < F_EB; ++e) {
                         const int c = code[e];
-                        const bool mv = c >= 0x80 && c < PAR_NONE;
-                        pos[e] += mv ? ((c >> 3) & 7) * F_P + (c & 7) - (2 * F_P + 2) : 0;
-                        code[e] = s_par[pos[e]];
-                        moving |= mv;
+                        pos[e] += (int)((c >> 3) & 7) * F_P + (c & 7) - (2 * F_P + 2);
                     }
-                    if (!__any(moving)) break;
-                }
-                // rare: a walker stands on a halo cell nobody has evaluated yet
 #pragma unroll
-                for (int e = 0; e < F_EB; ++e) {
-                    if (code[e] < 0x80) {
-                        const int r_ = pos[e] / F_P;
-                        const int c = fused_parent(s_x + FX(r_, pos[e] - r_ * F_P));
-                        s_par[pos[e]] = (u8)c;  // same value from every writer
-                        code[e] = c;
-                    }
+                    for (int e = 0; e < F_EB; ++e) code[e] = s_par[pos[e]];
                 }
-                // done only when every walker stands on a terminal cell.  (Not "nobody moved and nobody
-                // was stuck": another wave may have just written the code of a cell a stalled walker
-                // stands on, and the re-read above has then picked up a tap code in an iteration that
-                // did not move.)
-                bool pending = false;
+                int notdone = 0;
 #pragma unroll
-                for (int e = 0; e < F_EB; ++e) pending |= code[e] < PAR_NONE;
-                if (!__any(pending)) break;
+                for (int e = 0; e < F_EB; ++e) notdone |= (code[e] | 0x40) ^ F_NONE;  // 0 iff step (0,0)
+                if (!__any(notdone != 0)) break;
             }
-            if (stop_after == 5) {  // timing only: keep the walk alive, skip the rest
+            if (stop_after == 3) {  // timing only: keep the walk alive, skip the rest
 #pragma unroll
                 for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(pos[e]));
                 continue;
             }
-            int lab[F_EB], spx[F_EB];
+            int lab[F_EB], goff[F_EB], dd[F_EB];
             float val[F_EB];
+            bool bad = false;
+            const float *gbase = misaligned ? vlist + fo : x + fo;  // block-uniform
 #pragma unroll
             for (int e = 0; e < F_EB; ++e) {
-                // a valid chain ends on a source inside the in-image window; the clamps only make sure
+                // a decided chain ends on a source inside the in-image window; the clamps only make sure
                 // that a logic error could never become a wild global access
                 const int pr_ = pos[e] / F_P, pc_ = pos[e] - pr_ * F_P;
                 const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
+                const int tr = min(trb + e * NWAVE, th - 1);
+                dd[e] = abs(r_ - (FR + tr)) + abs(c_ - cc);  // L1 distance to the nearest source IS d
                 const int gj = wc0 + c_;
-                const int k = r_ * (F_NW32 / 2) + (gj >> 6) - w0;
+                const int k = r_ * 4 + (gj >> 6) - w0;
                 const u32 lo = s_sb[2 * k], hi = s_sb[2 * k + 1];
                 const u32 below = (1u << (gj & 31)) - 1u;
                 lab[e] = (int)s_rk[k] + ((gj & 32) ? __popc(lo) + __popc(hi & below) : __popc(lo & below)) + 1;
-                spx[e] = (wr0 + r_) * W + gj;
+                // depth_list[label-1] (tools.py:26).  A decided pixel has label >= 1, so the numpy wrap of
+                // index -1 cannot occur here; an index past the value list is numpy's IndexError.
+                const int idx = lab[e] - 1;
+                const bool oob = idx >= nval;
+                bad |= ok[e] && oob;
+                goff[e] = oob ? 0 : (misaligned ? idx : (wr0 + r_) * W + gj);  // masks agree: the label-th value is x at the source
             }
-            if (stop_after == 6) {
 #pragma unroll
-                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(lab[e]), "v"(spx[e]));
+            for (int e = 0; e < F_EB; ++e) val[e] = gbase[goff[e]];
+            if (stop_after == 4) {
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(val[e]), "v"(lab[e]), "v"(dd[e]));
                 continue;
             }
-#pragma unroll
-            for (int e = 0; e < F_EB; ++e)
-                if (ok[e] && out_depth)
-                    val[e] = gather_depth(x + fo, vlist + fo, lab[e], spx[e], nval, misaligned, frame_status + b);
-            if (stop_after == 7) {
-#pragma unroll
-                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(val[e]));
-                continue;
-            }
+            if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
 #pragma unroll
             for (int e = 0; e < F_EB; ++e) {
                 if (!ok[e]) continue;
