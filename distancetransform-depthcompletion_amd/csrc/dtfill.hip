@@ -99,6 +99,15 @@ __device__ __forceinline__ u16 st16(int v) { return (u16)(v >= INF16 ? INF16 : v
 // ------------------------------------------------------------------------------------------------
 constexpr int M_RPW = 4;  // image rows per wave in k_mask (independent loads in flight)
 
+__device__ __forceinline__ u32 wave_incl_sum(u32 v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_mask(const float *__restrict__ x, int H, int W, int Wd,
                                               float src_thr, float val_thr, u64 *__restrict__ srcbits,
                                               u64 *__restrict__ valbits, u16 *__restrict__ wpre_s,
@@ -107,40 +116,55 @@ __global__ __launch_bounds__(256) void k_mask(const float *__restrict__ x, int H
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = (blockIdx.x * 4 + wave) * M_RPW, b = blockIdx.y;
     if (i0 >= H) return;
-    u32 ps[M_RPW], pv[M_RPW], mis[M_RPW];
+    u32 run_s[M_RPW], run_v[M_RPW], mis[M_RPW];
 #pragma unroll
-    for (int q = 0; q < M_RPW; ++q) ps[q] = pv[q] = mis[q] = 0;
-    for (int k = 0; k < Wd; ++k) {
-        const int j = k * 64 + lane;
-        float v[M_RPW];
+    for (int q = 0; q < M_RPW; ++q) run_s[q] = run_v[q] = mis[q] = 0;
+    // 64 words (4096 pixels) of every row per chunk: lane k ends up holding word k0 + k of each row, so the
+    // words and their prefix counts leave as ONE coalesced store per row and array
+    for (int k0 = 0; k0 < Wd; k0 += 64) {
+        const int nk = min(64, Wd - k0);
+        u64 ws[M_RPW], wv[M_RPW];
 #pragma unroll
-        for (int q = 0; q < M_RPW; ++q) {
-            const int i = min(i0 + q, H - 1);
-            v[q] = j < W ? x[((size_t)b * H + i) * W + j] : 0.0f;
+        for (int q = 0; q < M_RPW; ++q) ws[q] = wv[q] = 0;
+#pragma unroll 2
+        for (int k = 0; k < nk; ++k) {
+            const int j = (k0 + k) * 64 + lane;
+            float v[M_RPW];
+#pragma unroll
+            for (int q = 0; q < M_RPW; ++q) {
+                const int i = min(i0 + q, H - 1);
+                v[q] = j < W ? x[((size_t)b * H + i) * W + j] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < M_RPW; ++q) {
+                const u64 sb = __ballot(j < W && !((1.0f - v[q]) > src_thr));
+                const u64 vb = __ballot(j < W && (v[q] > val_thr));
+                ws[q] = lane == k ? sb : ws[q];
+                wv[q] = lane == k ? vb : wv[q];
+            }
         }
 #pragma unroll
         for (int q = 0; q < M_RPW; ++q) {
-            const bool s = j < W && !((1.0f - v[q]) > src_thr);
-            const bool isv = j < W && (v[q] > val_thr);
-            const u64 sb = __ballot(s), vb = __ballot(isv);
-            if (lane == 0 && i0 + q < H) {
-                const size_t wi = ((size_t)b * H + i0 + q) * Wd + k;
-                srcbits[wi] = sb;
-                valbits[wi] = vb;
-                wpre_s[wi] = (u16)ps[q];
-                wpre_v[wi] = (u16)pv[q];
+            const u32 cs = __popcll(ws[q]), cv = __popcll(wv[q]);
+            const u32 is = wave_incl_sum(cs, lane), iv = wave_incl_sum(cv, lane);
+            mis[q] |= __any(ws[q] != wv[q]) ? 1u : 0u;
+            if (lane < nk && i0 + q < H) {
+                const size_t wi = ((size_t)b * H + i0 + q) * Wd + k0 + lane;
+                srcbits[wi] = ws[q];
+                valbits[wi] = wv[q];
+                wpre_s[wi] = (u16)(run_s[q] + is - cs);
+                wpre_v[wi] = (u16)(run_v[q] + iv - cv);
             }
-            ps[q] += __popcll(sb);
-            pv[q] += __popcll(vb);
-            mis[q] |= (sb != vb);
+            run_s[q] += __shfl(is, 63);
+            run_v[q] += __shfl(iv, 63);
         }
     }
     if (lane == 0) {
 #pragma unroll
         for (int q = 0; q < M_RPW; ++q)
             if (i0 + q < H) {
-                rowcnt_s[(size_t)b * H + i0 + q] = ps[q];
-                rowcnt_v[(size_t)b * H + i0 + q] = pv[q] | (mis[q] ? 0x80000000u : 0u);
+                rowcnt_s[(size_t)b * H + i0 + q] = run_s[q];
+                rowcnt_v[(size_t)b * H + i0 + q] = run_v[q] | (mis[q] ? 0x80000000u : 0u);
             }
     }
 }
