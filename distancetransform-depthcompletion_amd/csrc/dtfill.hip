@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
                                                const u32 *__restrict__ rowcnt_v, int H, int W, int Wd,
                                                u32 *__restrict__ rowbase_s, u32 *__restrict__ rowbase_v,
                                                int *__restrict__ finfo, float *__restrict__ vlist,
-                                               int *__restrict__ fflag, int *__restrict__ frame_status,
-                                               int force_general) {
+                                               int *__restrict__ fflag, int *__restrict__ fflag2,
+                                               int *__restrict__ frame_status, int force_general) {
     __shared__ u32 s_ws[4], s_wv[4];
     __shared__ int s_mis;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         finfo[b * FI_STRIDE + FI_NSRC] = (int)run_s;
         finfo[b * FI_STRIDE + FI_NVAL] = (int)run_v;
         finfo[b * FI_STRIDE + FI_MISALIGNED] = misaligned;
-        fflag[b] = force_general ? 1 : 0;
+        fflag[b] = 0;                       // set by k_fused<16>: the frame needs a wider halo
+        fflag2[b] = force_general ? 1 : 0;  // set by k_fused<32>: the frame needs the general path
         frame_status[b] = force_general ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
     }
     if (misaligned) {
@@ -298,10 +299,8 @@ __device__ __forceinline__ float gather_depth(const float *__restrict__ xf, cons
 // lock-step; d is |drow| + |dcol| to the root.
 // LDS: 25.3 KB ring/s_par + 6 KB bit words and ranks.
 // ------------------------------------------------------------------------------------------------
-constexpr int FR = 16;
-constexpr int F_THM = 96, F_TWM = 160;
-constexpr int F_WHM = F_THM + 2 * FR;  // 128 rows = lanes of two waves
-constexpr int F_WWM = F_TWM + 2 * FR;  // 192 columns = 6 words
+constexpr int F_WHM = 128;  // window rows = lanes of two waves
+constexpr int F_WWM = 192;  // window columns = 6 words
 constexpr int F_NT = 128;
 constexpr int F_P = 196;               // s_par row pitch: 49 dwords (odd) -> lane-per-row dword stores are conflict-free
 constexpr int F_NWD = 6;               // 32-bit words per window row
@@ -352,12 +351,30 @@ __device__ __forceinline__ void ring_store(u32 *__restrict__ ring, int slot, int
     for (int i = 0; i < F_NWD / 2; ++i) p[i] = make_uint2(w[2 * i], w[2 * i + 1]);
 }
 
+// FR = halo = largest distance the window can decide.  gate (nullable): only frames with gate[b] != 0
+// are processed (the second, FR = 32 stage only redoes the frames the FR = 16 stage flagged).
+template <int FR>
 __global__ __launch_bounds__(F_NT) void k_fused(
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
     const u32 *__restrict__ rowbase_s, const int *__restrict__ finfo, const float *__restrict__ vlist,
     int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
-    float *__restrict__ out_dt, int32_t *__restrict__ out_index, int *__restrict__ fflag,
-    int *__restrict__ frame_status, int stop_after) {
+    float *__restrict__ out_dt, int32_t *__restrict__ out_index, const int *__restrict__ gate,
+    int *__restrict__ fflag, int *__restrict__ frame_status, int stop_after) {
+    if (gate && !gate[blockIdx.y]) return;
+    {
+        // Speed heuristic only (never correctness): with source density p the chance that a pixel has
+        // no source within L1 distance FR is about (1-p)^(2 FR^2 + 2 FR + 1); if the frame is expected to
+        // hold such a pixel anyway (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), this stage would only
+        // flag the frame after doing all the work -- hand it on right away.
+        const long long nsrc = finfo[blockIdx.y * FI_STRIDE + FI_NSRC];
+        if (nsrc * (2 * FR * FR + 2 * FR + 1) < 14ll * H * W) {
+            if (threadIdx.x == 0 && blockIdx.x == 0) {
+                fflag[blockIdx.y] = 1;
+                if (FR == 32) atomicOr(frame_status + blockIdx.y, DTFILL_FRAME_GENERAL_PATH);
+            }
+            return;
+        }
+    }
     __shared__ __attribute__((aligned(16))) u32 s_ring[4 * 2 * F_RROWS * F_NWD];  // later: s_par bytes
     __shared__ u32 s_sb[F_WHM * 8];  // source bits of the window rows, image-aligned 64-pixel words (as u32 pairs)
     __shared__ u32 s_rk[F_WHM * 4];  // sources before each of those 64-pixel words (frame raster order)
@@ -612,7 +629,7 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     }
     if (overflow) {
         fflag[b] = 1;  // same-value race
-        atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);
+        if (FR == 32) atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);  // last fused stage: general path next
     }
 }
 
@@ -839,7 +856,7 @@ struct Carve {
     u64 *srcbits, *valbits;
     u16 *wpre_s, *wpre_v;
     u32 *rowcnt_s, *rowcnt_v, *rowbase_s, *rowbase_v;
-    int *finfo, *fflag, *status;
+    int *finfo, *fflag, *fflag2, *status;
     float *vlist;
     size_t total;
 };
@@ -867,6 +884,7 @@ Carve carve(void *ws, int B, int H, int W) {
     c.rowbase_v = (u32 *)take(NR * 4);
     c.finfo = (int *)take((size_t)B * FI_STRIDE * 4);
     c.fflag = (int *)take((size_t)B * 4);
+    c.fflag2 = (int *)take((size_t)B * 4);
     c.status = (int *)take((size_t)B * 4);
     // general-path arrays (touched only for frames the fused kernel flags)
     c.gu = (u16 *)take(N * 2);
@@ -909,32 +927,44 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
                                                 c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s,
-                               c.rowbase_v, c.finfo, c.vlist, c.fflag, status, general_only ? 1 : 0);
+                               c.rowbase_v, c.finfo, c.vlist, c.fflag, c.fflag2, status, general_only ? 1 : 0);
     mark();
     if (!general_only) {
-        const int nty = (H + F_THM - 1) / F_THM, ntx = (W + F_TWM - 1) / F_TWM;
-        const int TH = (H + nty - 1) / nty, TW = (W + ntx - 1) / ntx;  // even split, <= F_THM x F_TWM
-        k_fused<<<dim3(ntx * nty, B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H,
-                                                   W, Wd, TH, TW, ntx, out_depth, out_dt, out_index,
-                                                   c.fflag, status, fused_stop);
+        // stage 1: halo 16 (tiles up to 96 x 160); stage 2, only for frames stage 1 flagged: halo 32
+        {
+            constexpr int R = 16, THM = F_WHM - 2 * R, TWM = F_WWM - 2 * R;
+            const int nty = (H + THM - 1) / THM, ntx = (W + TWM - 1) / TWM;
+            const int TH = (H + nty - 1) / nty, TW = (W + ntx - 1) / ntx;  // even split
+            k_fused<R><<<dim3(ntx * nty, B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist,
+                                                           H, W, Wd, TH, TW, ntx, out_depth, out_dt, out_index,
+                                                           nullptr, c.fflag, status, fused_stop);
+        }
+        {
+            constexpr int R = 32, THM = F_WHM - 2 * R, TWM = F_WWM - 2 * R;
+            const int nty = (H + THM - 1) / THM, ntx = (W + TWM - 1) / TWM;
+            const int TH = (H + nty - 1) / nty, TW = (W + ntx - 1) / ntx;
+            k_fused<R><<<dim3(ntx * nty, B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist,
+                                                           H, W, Wd, TH, TW, ntx, out_depth, out_dt, out_index,
+                                                           c.fflag, c.fflag2, status, -1);
+        }
     }
     mark();
     if (!fused_only) {
-        k_colscan<<<dim3(Wd, B), 64, 0, st>>>(c.srcbits, c.fflag, H, W, Wd, c.gu, c.g);
+        k_colscan<<<dim3(Wd, B), 64, 0, st>>>(c.srcbits, c.fflag2, H, W, Wd, c.gu, c.g);
         mark();
         const int nU = W + 2 * (H - 1) + 1;
-        k_skew<<<dim3((nU + 63) / 64, B), 64, 0, st>>>(c.gu, c.fflag, H, W, c.dB);
+        k_skew<<<dim3((nU + 63) / 64, B), 64, 0, st>>>(c.gu, c.fflag2, H, W, c.dB);
         mark();
         const int ngroups = Wd;
         const size_t per_wave = (size_t)ngroups * 128 * sizeof(u16);  // <= 32 KiB at W = 8191
         const int wpb = (int)max((size_t)1, min((size_t)4, (size_t)65536 / per_wave));
-        k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag, H,
+        k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag2, H,
                                                                               W, ngroups, c.dl);
         mark();
-        k_parent<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(c.dl, c.fflag, H, W, c.par);
+        k_parent<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(c.dl, c.fflag2, H, W, c.par);
         mark();
         k_resolve<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(x, c.dl, c.par, c.srcbits, c.wpre_s,
-                                                            c.rowbase_s, c.finfo, c.vlist, c.fflag, H, W, Wd,
+                                                            c.rowbase_s, c.finfo, c.vlist, c.fflag2, H, W, Wd,
                                                             out_depth, out_dt, out_index, status);
         mark();
     } else {

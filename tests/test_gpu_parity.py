@@ -203,20 +203,24 @@ def test_fused_kernel_alone_decides_dense_frames(gpu_op, oracle, pkg):
     got = run(gpu_op, x, path="fused")
     assert not got["general"].any()
     assert np.array_equal(got["dt"], dt) and np.array_equal(got["index"], lbl) and np.array_equal(got["depth"], depth)
-    x[2, 100:160] = 0
+    # an empty band of 40 rows: distances up to ~25 -> beyond the halo-16 stage, within the halo-32 stage
+    x[1, 100:140] = 0
+    # an empty band of 90 rows: distances up to ~45 -> only the general (any-distance) kernels can decide it
+    x[2, 100:190] = 0
+    depth2, dt2, lbl2, _ = oracle.fill_batch(x)
     got = run(gpu_op, x, path="fused")
     assert got["general"].tolist() == [False, False, True, False]
     for b in (0, 1, 3):
-        assert np.array_equal(got["index"][b], lbl[b]) and np.array_equal(got["depth"][b], depth[b])
+        assert np.array_equal(got["index"][b], lbl2[b]) and np.array_equal(got["depth"][b], depth2[b])
+        assert np.array_equal(got["dt"][b], dt2[b])
     auto = run(gpu_op, x)
-    depth2, dt2, lbl2, _ = oracle.fill_batch(x)
     assert auto["general"].tolist() == [False, False, True, False]
     assert np.array_equal(auto["dt"], dt2) and np.array_equal(auto["index"], lbl2) and np.array_equal(auto["depth"], depth2)
 
 
 def test_tile_seams_and_halo_boundary(gpu_op, oracle):
-    """Distances exactly at / one past the halo (16), sources on tile seams, odd frame sizes that
-    make ragged last tiles."""
+    """Distances exactly at / one past the halos (16 and 32), sources on tile seams, odd frame sizes
+    that make ragged last tiles."""
     for H, W in [(88, 152), (89, 153), (176, 304), (100, 321), (33, 40), (17, 500)]:
         x = np.zeros((3, H, W), np.float32)
         x[0, ::17, ::17] = 2.0   # lattice with max L1 distance 16: exactly the halo
@@ -224,6 +228,10 @@ def test_tile_seams_and_halo_boundary(gpu_op, oracle):
         x[2, H // 2, :] = 4.0    # a full row of sources: vertical distances up to H/2
         x[2, :, W // 2] = 5.0
         assert_equal_to_oracle(oracle, gpu_op, x)
+        y = np.zeros((2, H, W), np.float32)
+        y[0, ::33, ::33] = 2.0   # max L1 distance 32: exactly the second halo
+        y[1, ::34, ::33] = 3.0   # ... 33
+        assert_equal_to_oracle(oracle, gpu_op, y)
     rng = np.random.default_rng(8)
     x = np.where(rng.random((2, 352, 1216)) < 0.012, rng.uniform(1, 80, (2, 352, 1216)), 0).astype(np.float32)
     assert_equal_to_oracle(oracle, gpu_op, x)  # 1.2 %: a mix of decided and flagged frames
