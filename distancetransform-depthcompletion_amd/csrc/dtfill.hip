@@ -637,27 +637,50 @@ __global__ __launch_bounds__(F_NT) void k_fused(
 // General path (any distance).  Every kernel returns at once for frames k_fused did not flag.
 // ================================================================================================
 
-// k_colscan: one lane per image column, 64 adjacent columns per wave.
-//   down sweep: gu(i,j) = rows to the nearest source at or above (i,j); up sweep: g = min(gu, gd).
-__global__ __launch_bounds__(64) void k_colscan(const u64 *__restrict__ srcbits, const int *__restrict__ fflag,
-                                                int H, int W, int Wd, u16 *__restrict__ gu,
-                                                u16 *__restrict__ g) {
-    const int b = blockIdx.y, wd = blockIdx.x, lane = threadIdx.x;
+constexpr int G_NCH = 16;  // row chunks (= waves per block) of the chunked column / knight-line scans
+
+// k_colscan: 64 adjacent image columns per block, one wave per chunk of rows.
+//   pass A: last / first source row of every column inside the chunk -> LDS
+//   pass B: carry in the nearest source row above / below the chunk, then
+//           down sweep: gu(i,j) = rows to the nearest source at or above (i,j);  up sweep: g = min(gu, gd).
+__global__ __launch_bounds__(64 * G_NCH) void k_colscan(const u64 *__restrict__ srcbits,
+                                                        const int *__restrict__ fflag, int H, int W, int Wd,
+                                                        int CR, u16 *__restrict__ gu, u16 *__restrict__ g) {
+    __shared__ int s_last[G_NCH][64], s_first[G_NCH][64];
+    const int b = blockIdx.y, wd = blockIdx.x, lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
     if (!fflag[b]) return;
     const int j = wd * 64 + lane;
     const bool inb = j < W;
     const size_t fo = (size_t)b * H * W;
     u16 *guf = gu + fo, *gf = g + fo;
     const u64 *sbf = srcbits + (size_t)b * H * Wd + wd;
+    const int i0 = min(ch * CR, H), i1 = min(i0 + CR, H);
 
-    int up = BIG;
-    for (int i = 0; i < H; ++i) {
+    int last = -BIG, first = BIG;
+    for (int i = i0; i < i1; ++i) {
+        const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
+        last = s ? i : last;
+        first = s ? min(first, i) : first;
+    }
+    s_last[ch][lane] = last;
+    s_first[ch][lane] = first;
+    __syncthreads();
+    int above = -BIG, below = BIG;
+#pragma unroll
+    for (int c = 0; c < G_NCH; ++c) {
+        above = c < ch ? max(above, s_last[c][lane]) : above;
+        below = c > ch ? min(below, s_first[c][lane]) : below;
+    }
+    int up = min(i0 - 1 - above, BIG);  // value "at row i0-1"
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) {
         const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
         up = s ? 0 : min(up + 1, BIG);
         if (inb) guf[(size_t)i * W + j] = st16(up);
     }
-    int dn = BIG;
-    for (int i = H - 1; i >= 0; --i) {
+    int dn = min(below - i1, BIG);  // value "at row i1"
+#pragma unroll 4
+    for (int i = i1 - 1; i >= i0; --i) {
         const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
         dn = s ? 0 : min(dn + 1, BIG);
         if (inb) {
@@ -667,12 +690,36 @@ __global__ __launch_bounds__(64) void k_colscan(const u64 *__restrict__ srcbits,
     }
 }
 
-// k_skew: one lane per knight line u = j + 2 i over the extended column range j in [0, W]
-// (column W is virtual: E(i,W) = gu(i,W-1) - 1).  All lanes of a wave sit in the same image row at
-// each step, so the gu reads and dB writes of a step are contiguous.
-__global__ __launch_bounds__(64) void k_skew(const u16 *__restrict__ gu, const int *__restrict__ fflag,
-                                             int H, int W, u16 *__restrict__ dB) {
-    const int b = blockIdx.y, lane = threadIdx.x;
+// k_skew: knight lines u = j + 2 i over the extended column range j in [0, W] (column W is virtual:
+// E(i,W) = gu(i,W-1) - 1).  64 adjacent lines per block, one wave per chunk of the rows those lines
+// cross; all lanes of a wave sit in the same image row at each step, so the gu reads and dB writes
+// of a step are contiguous.  D(i) = min(E(i), 3 + D(i-1)) is scanned per chunk from "infinity"
+// (pass A), the true value at each chunk start follows from the chunk ends (LDS), and pass B rescans
+// from it and stores dB = 3 + D(previous row).
+__device__ __forceinline__ int skew_step(const u16 *__restrict__ guf, u16 *__restrict__ dBf, int W, int nU,
+                                         int u, int i, int D) {
+    const int j = u - 2 * i;
+    const bool on = (u < nU) && j >= 0 && j <= W;
+    const int dbv = min(D + 3, BIG);  // 3 + D(i-1, j+2)
+    int e = BIG;
+    if (on) {
+        const u16 *row = guf + (size_t)i * W;
+        if (j < W) {
+            if (dBf) dBf[(size_t)i * W + j] = st16(dbv);
+            e = ld16(row + j);
+        }
+        if (j >= 1) {
+            const int t = ld16(row + j - 1);
+            if (t < BIG) e = min(e, t - 1);
+        }
+    }
+    return on ? min(e, dbv) : BIG;
+}
+
+__global__ __launch_bounds__(64 * G_NCH) void k_skew(const u16 *__restrict__ gu, const int *__restrict__ fflag,
+                                                     int H, int W, u16 *__restrict__ dB) {
+    __shared__ int s_end[G_NCH][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
     if (!fflag[b]) return;
     const int nU = W + 2 * (H - 1) + 1;
     const int u0 = blockIdx.x * 64;
@@ -682,27 +729,26 @@ __global__ __launch_bounds__(64) void k_skew(const u16 *__restrict__ gu, const i
     const u16 *guf = gu + fo;
     u16 *dBf = dB + fo;
 
-    const int i_lo = max(0, (u0 - W + 1) / 2);  // first row any lane of this wave is inside [0, W]
+    const int i_lo = max(0, (u0 - W + 1) / 2);  // first row any lane of this block is inside [0, W]
     const int i_hi = min(H - 1, u1 / 2);
+    const int CR = (i_hi - i_lo + 1 + G_NCH - 1) / G_NCH;
+    const int c0 = min(i_lo + ch * CR, i_hi + 1), c1 = min(c0 + CR, i_hi + 1);
     int D = BIG;
-    for (int i = i_lo; i <= i_hi; ++i) {
-        const int j = u - 2 * i;
-        const bool on = (u < nU) && j >= 0 && j <= W;
-        const int dbv = min(D + 3, BIG);  // 3 + D(i-1, j+2); D is BIG until the lane's line starts
-        int e = BIG;
-        if (on) {
-            const u16 *row = guf + (size_t)i * W;
-            if (j < W) {
-                dBf[(size_t)i * W + j] = st16(dbv);
-                e = ld16(row + j);
-            }
-            if (j >= 1) {
-                int t = ld16(row + j - 1);
-                if (t < BIG) e = min(e, t - 1);
-            }
-        }
-        D = on ? min(e, dbv) : BIG;
+    for (int i = c0; i < c1; ++i) D = skew_step(guf, nullptr, W, nU, u, i, D);
+    s_end[ch][lane] = D;
+    __syncthreads();
+    // D just before row c0: chain the chunk ends (a line is "on" for one contiguous row range, and an
+    // "off" row resets D to BIG exactly as in the local scans)
+    int K = BIG;
+    for (int c = 0; c < ch; ++c) {
+        const int len = min(i_lo + (c + 1) * CR, i_hi + 1) - min(i_lo + c * CR, i_hi + 1);
+        K = min(s_end[c][lane], min(K + 3 * len, BIG));
+        // a line that was off at the end of chunk c has s_end == BIG and, being contiguous, was never on
+        // before: K + 3 len stays >= BIG only if K was BIG -- which holds, because any earlier on-rows
+        // would make the line on at the end of chunk c as well (it leaves the image only at its last row)
     }
+    D = K;
+    for (int i = c0; i < c1; ++i) D = skew_step(guf, dBf, W, nU, u, i, D);
 }
 
 // k_rowscan: one wave per image row.  d(i,j) = min_k g(i,k) + |j-k| as prefix-min of (g-k) plus
@@ -950,10 +996,10 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     }
     mark();
     if (!fused_only) {
-        k_colscan<<<dim3(Wd, B), 64, 0, st>>>(c.srcbits, c.fflag2, H, W, Wd, c.gu, c.g);
+        k_colscan<<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, c.fflag2, H, W, Wd, (H + G_NCH - 1) / G_NCH, c.gu, c.g);
         mark();
         const int nU = W + 2 * (H - 1) + 1;
-        k_skew<<<dim3((nU + 63) / 64, B), 64, 0, st>>>(c.gu, c.fflag2, H, W, c.dB);
+        k_skew<<<dim3((nU + 63) / 64, B), 64 * G_NCH, 0, st>>>(c.gu, c.fflag2, H, W, c.dB);
         mark();
         const int ngroups = Wd;
         const size_t per_wave = (size_t)ngroups * 128 * sizeof(u16);  // <= 32 KiB at W = 8191
