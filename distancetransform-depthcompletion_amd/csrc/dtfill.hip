@@ -854,9 +854,77 @@ __global__ __launch_bounds__(256) void k_parent(const u16 *__restrict__ dl, cons
     }
 }
 
-// k_resolve: walk the parent chain to its source, label, gather, store.
-__global__ __launch_bounds__(256) void k_resolve(
-    const float *__restrict__ x, const u16 *__restrict__ dl, const u8 *__restrict__ par,
+// k_exit: one block per 128 x 128 tile of parent codes.  Inside the tile the chains are resolved by
+// pointer doubling in LDS (every cell does the same work each round: no divergent walks, and the number
+// of rounds is log2 of the longest in-tile chain, whatever the distances are).  A cell is terminal if it
+// is a source, has no parent, or its parent lies outside the tile.  Result per pixel: an exit pointer
+//   bit 31 set : the chain's root source, pixel index in the low bits
+//   0x7FFFFFFF : no source in the frame
+//   otherwise  : pixel index (another tile) where the chain continues
+constexpr int X_T = 128;             // tile edge
+constexpr u32 X_ROOT = 0x80000000u;  // exit pointer: resolved to a root
+constexpr u32 X_NONE = 0x7FFFFFFFu;  // exit pointer: frame without sources
+
+__global__ __launch_bounds__(256) void k_exit(const u8 *__restrict__ par, const int *__restrict__ fflag, int H,
+                                              int W, int tiles_x, u32 *__restrict__ exitp) {
+    __shared__ u8 s_code[X_T * X_T];
+    __shared__ u16 s_ptr[X_T * X_T];
+    const int b = blockIdx.y;
+    if (!fflag[b]) return;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int r0 = ty * X_T, c0 = tx * X_T;
+    const size_t fo = (size_t)b * H * W;
+    const u8 *parf = par + fo;
+    const int tid = threadIdx.x;
+
+    for (int k = tid; k < X_T * X_T; k += 256) {
+        const int r = k >> 7, c = k & (X_T - 1);
+        const int gi = r0 + r, gj = c0 + c;
+        const int code = (gi < H && gj < W) ? (int)parf[(size_t)gi * W + gj] : PAR_NONE;
+        s_code[k] = (u8)code;
+        int di, dj;
+        tap_decode(code, di, dj);
+        const int nr = r + di, nc = c + dj;
+        const bool inside = code < 16 && nr >= 0 && nr < X_T && nc >= 0 && nc < X_T;
+        s_ptr[k] = inside ? (u16)(nr * X_T + nc) : (u16)(k | 0x8000);
+    }
+    __syncthreads();
+    for (int round = 0; round < 16; ++round) {  // 2^16 > any in-tile chain
+        bool open = false;
+        for (int k = tid; k < X_T * X_T; k += 256) {
+            const int p = s_ptr[k];
+            if (!(p & 0x8000)) {
+                const int q = s_ptr[p];  // any value seen here is an ancestor of k: races only speed things up
+                s_ptr[k] = (u16)q;
+                open |= !(q & 0x8000);
+            }
+        }
+        if (!__syncthreads_or(open)) break;
+    }
+    for (int k = tid; k < X_T * X_T; k += 256) {
+        const int r = k >> 7, c = k & (X_T - 1);
+        const int gi = r0 + r, gj = c0 + c;
+        if (gi >= H || gj >= W) continue;
+        const int t = s_ptr[k] & 0x3FFF;  // terminal cell of k's in-tile chain
+        const int code = s_code[t];
+        const int tr = r0 + (t >> 7), tc = c0 + (t & (X_T - 1));
+        u32 e;
+        if (code == PAR_SRC) {
+            e = X_ROOT | (u32)(tr * W + tc);
+        } else if (code >= 16) {
+            e = X_NONE;
+        } else {
+            int di, dj;
+            tap_decode(code, di, dj);
+            e = (u32)min(max((tr + di) * W + tc + dj, 0), H * W - 1);  // clamp: a logic error must not become a wild access
+        }
+        exitp[fo + (size_t)gi * W + gj] = e;
+    }
+}
+
+// k_final: follow the exit pointers from tile to tile (a chain crosses few tiles), then label, gather, store.
+__global__ __launch_bounds__(256) void k_final(
+    const float *__restrict__ x, const u16 *__restrict__ dl, const u32 *__restrict__ exitp,
     const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
     const int *__restrict__ finfo, const float *__restrict__ vlist, const int *__restrict__ fflag, int H,
     int W, int Wd, float *__restrict__ out_depth, float *__restrict__ out_dt,
@@ -864,30 +932,25 @@ __global__ __launch_bounds__(256) void k_resolve(
     const int b = blockIdx.y;
     if (!fflag[b]) return;
     const size_t fo = (size_t)b * H * W;
-    const u8 *parf = par + fo;
+    const u32 *ef = exitp + fo;
     for (int p = blockIdx.x * (256 * G_PPT) + threadIdx.x, n = 0; n < G_PPT && p < H * W; ++n, p += 256) {
-    int q = p;
-    int code = parf[q];
-    for (int hop = 0; code < 16 && hop < MAX_HW_SUM; ++hop) {
-        int di, dj;
-        tap_decode(code, di, dj);
-        q = min(max(q + di * W + dj, 0), H * W - 1);  // clamp: a logic error must not become a wild access
-        code = parf[q];
-    }
-    int label = 0;
-    if (code == PAR_SRC) {
-        const int i = q / W, j = q - i * W;
-        const size_t w = ((size_t)b * H + i) * Wd + (j >> 6);
-        label = source_rank(rowbase_s[(size_t)b * H + i] + wpre_s[w], srcbits[w], j);
-    }
-    if (out_index) out_index[fo + p] = label;
-    if (out_dt) {
-        const int d = dl[fo + p] & DL_DMASK;
-        out_dt[fo + p] = d == DL_NONE ? 8192.0f : (float)d;  // float(INIT_DIST0 * 2^-16) == 8192.0f
-    }
-    if (out_depth)
-        out_depth[fo + p] = gather_depth(x + fo, vlist + fo, label, q, finfo[b * FI_STRIDE + FI_NVAL],
-                                         finfo[b * FI_STRIDE + FI_MISALIGNED], frame_status + b);
+        u32 e = ef[p];
+        for (int hop = 0; hop < MAX_HW_SUM && !(e & X_ROOT) && e != X_NONE; ++hop) e = ef[e];
+        int label = 0, q = p;
+        if (e & X_ROOT) {
+            q = (int)(e & ~X_ROOT);
+            const int i = q / W, j = q - i * W;
+            const size_t w = ((size_t)b * H + i) * Wd + (j >> 6);
+            label = source_rank(rowbase_s[(size_t)b * H + i] + wpre_s[w], srcbits[w], j);
+        }
+        if (out_index) out_index[fo + p] = label;
+        if (out_dt) {
+            const int d = dl[fo + p] & DL_DMASK;
+            out_dt[fo + p] = d == DL_NONE ? 8192.0f : (float)d;  // float(INIT_DIST0 * 2^-16) == 8192.0f
+        }
+        if (out_depth)
+            out_depth[fo + p] = gather_depth(x + fo, vlist + fo, label, q, finfo[b * FI_STRIDE + FI_NVAL],
+                                             finfo[b * FI_STRIDE + FI_MISALIGNED], frame_status + b);
     }
 }
 
@@ -899,6 +962,7 @@ inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 struct Carve {
     u16 *gu, *g, *dB, *dl;
     u8 *par;
+    u32 *exitp;
     u64 *srcbits, *valbits;
     u16 *wpre_s, *wpre_v;
     u32 *rowcnt_s, *rowcnt_v, *rowbase_s, *rowbase_v;
@@ -938,6 +1002,7 @@ Carve carve(void *ws, int B, int H, int W) {
     c.dB = (u16 *)take(N * 2);
     c.dl = (u16 *)take(N * 2);
     c.par = (u8 *)take(N);
+    c.exitp = (u32 *)take(N * 4);
     c.vlist = (float *)take(N * 4);
     c.total = off;
     return c;
@@ -948,9 +1013,9 @@ bool shape_ok(int B, int H, int W) {
            (long long)B * H * W < (1ll << 31);
 }
 
-constexpr int NK_L1 = 8;
-const char *const kNamesL1[NK_L1] = {"k_mask",  "k_frame",   "k_fused",  "k_colscan",
-                                     "k_skew",  "k_rowscan", "k_parent", "k_resolve"};
+constexpr int NK_L1 = 9;
+const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame",   "k_fused",  "k_colscan", "k_skew",
+                                     "k_rowscan", "k_parent", "k_exit",   "k_final"};
 
 int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, float *out_depth,
            float *out_dt, int32_t *out_index, int32_t *frame_status, void *workspace, unsigned flags,
@@ -1009,12 +1074,17 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         mark();
         k_parent<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(c.dl, c.fflag2, H, W, c.par);
         mark();
-        k_resolve<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(x, c.dl, c.par, c.srcbits, c.wpre_s,
-                                                            c.rowbase_s, c.finfo, c.vlist, c.fflag2, H, W, Wd,
-                                                            out_depth, out_dt, out_index, status);
+        {
+            const int etx = (W + X_T - 1) / X_T, ety = (H + X_T - 1) / X_T;
+            k_exit<<<dim3(etx * ety, B), 256, 0, st>>>(c.par, c.fflag2, H, W, etx, c.exitp);
+        }
+        mark();
+        k_final<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(
+            x, c.dl, c.exitp, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, c.fflag2, H, W, Wd, out_depth,
+            out_dt, out_index, status);
         mark();
     } else {
-        for (int t = 0; t < 5; ++t) mark();
+        for (int t = 0; t < 6; ++t) mark();
     }
     return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
