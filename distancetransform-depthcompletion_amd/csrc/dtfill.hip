@@ -66,7 +66,7 @@ constexpr int PAR_NONE = 0xFE;     // parent code: unreachable / undecided
 constexpr int MAX_HW_SUM = 8192;   // cv2's Q16 INIT_DIST0 = INT_MAX>>2 caps distances at 8191
 
 // frame facts written by k_frame: int32[FI_STRIDE] per frame
-constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_STRIDE = 4;
+constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_DLB = 3, FI_STRIDE = 4;  // DLB: lower bound of max d
 
 // cv2 tap order (OpenCV 3.4 distanceTransformEx_5x5), forward taps 0..7; backward tap t is the
 // NEGATED forward tap t with the same weight.  Parent code = t | (backward ? 8 : 0).
@@ -184,9 +184,10 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
                                                int *__restrict__ fflag, int *__restrict__ fflag2,
                                                int *__restrict__ frame_status, int force_general) {
     __shared__ u32 s_ws[4], s_wv[4];
-    __shared__ int s_mis;
+    __shared__ int s_mis, s_dlb;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 *cs_ = rowcnt_s + (size_t)b * H, *cv_ = rowcnt_v + (size_t)b * H;
+    if (tid == 0) s_dlb = 0;
     u32 *bs_ = rowbase_s + (size_t)b * H, *bv_ = rowbase_v + (size_t)b * H;
     if (tid == 0) s_mis = 0;
     __syncthreads();
@@ -234,12 +235,27 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         __syncthreads();
     }
     if (mis) atomicOr(&s_mis, 1);
+    // Lower bound of the largest distance in the frame from runs of rows without any source: a run of k
+    // empty rows forces d >= ceil(k/2) in its middle row, d >= k at the border row if it touches the top or
+    // bottom edge.  Each thread looks at the run ENDING at its rows (cheap: the counts are in L2).
+    {
+        int dlb = 0;
+        for (int i = tid; i < H; i += 256) {
+            if (cs_[i] != 0 || (i + 1 < H && cs_[i + 1] == 0)) continue;  // not the last row of a run
+            int k = 1;
+            while (i - k >= 0 && cs_[i - k] == 0) ++k;
+            const bool edge = (i - k < 0) || (i + 1 >= H);
+            dlb = max(dlb, (i - k < 0 && i + 1 >= H) ? BIG : edge ? k : (k + 1) / 2);
+        }
+        if (dlb) atomicMax(&s_dlb, dlb);
+    }
     __syncthreads();
     const int misaligned = s_mis;
     if (tid == 0) {
         finfo[b * FI_STRIDE + FI_NSRC] = (int)run_s;
         finfo[b * FI_STRIDE + FI_NVAL] = (int)run_v;
         finfo[b * FI_STRIDE + FI_MISALIGNED] = misaligned;
+        finfo[b * FI_STRIDE + FI_DLB] = s_dlb;
         fflag[b] = 0;                       // set by k_fused<16>: the frame needs a wider halo
         fflag2[b] = force_general ? 1 : 0;  // set by k_fused<32>: the frame needs the general path
         frame_status[b] = force_general ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
@@ -365,9 +381,10 @@ __global__ __launch_bounds__(F_NT) void k_fused(
         // Speed heuristic only (never correctness): with source density p the chance that a pixel has
         // no source within L1 distance FR is about (1-p)^(2 FR^2 + 2 FR + 1); if the frame is expected to
         // hold such a pixel anyway (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), this stage would only
-        // flag the frame after doing all the work -- hand it on right away.
+        // flag the frame after doing all the work -- hand it on right away.  Likewise when k_frame found a run
+        // of source-free rows that forces some distance above FR (real LiDAR frames: the empty sky rows).
         const long long nsrc = finfo[blockIdx.y * FI_STRIDE + FI_NSRC];
-        if (nsrc * (2 * FR * FR + 2 * FR + 1) < 14ll * H * W) {
+        if (nsrc * (2 * FR * FR + 2 * FR + 1) < 14ll * H * W || finfo[blockIdx.y * FI_STRIDE + FI_DLB] > FR) {
             if (threadIdx.x == 0 && blockIdx.x == 0) {
                 fflag[blockIdx.y] = 1;
                 if (FR == 32) atomicOr(frame_status + blockIdx.y, DTFILL_FRAME_GENERAL_PATH);
@@ -818,70 +835,71 @@ __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, cons
     }
 }
 
-constexpr int G_PPT = 16;  // pixels per thread in k_parent / k_resolve (keeps their no-op grids small)
+constexpr int G_PPT = 16;  // pixels per thread in k_final (keeps its no-op grid small)
 
-// k_parent: the 5x5 rule, full frame through L2.
-__global__ __launch_bounds__(256) void k_parent(const u16 *__restrict__ dl, const int *__restrict__ fflag,
-                                                int H, int W, u8 *__restrict__ par) {
-    const int b = blockIdx.y;
-    if (!fflag[b]) return;
-    const size_t fo = (size_t)b * H * W;
-    const u16 *dlf = dl + fo;
-    for (int p = blockIdx.x * (256 * G_PPT) + threadIdx.x, n = 0; n < G_PPT && p < H * W; ++n, p += 256) {
-    const int q = dlf[p];
-    const int d = q & DL_DMASK;
-    int code;
-    if (d == 0) {
-        code = PAR_SRC;
-    } else if (d == DL_NONE) {
-        code = PAR_NONE;
-    } else {
-        const int i = p / W, j = p - i * W;
-        const int live = (q & DL_LIVE) ? 1 : 0;
-        const int sgn = live ? 1 : -1;
-        code = PAR_NONE;
-#pragma unroll
-        for (int t = 7; t >= 0; --t) {  // descending so the FIRST matching tap is the one kept
-            const int r = i + sgn * TAP_DI(t), c = j + sgn * TAP_DJ(t);
-            if (r >= 0 && r < H && c >= 0 && c < W) {
-                const int v = dlf[r * W + c];
-                const bool ok = ((v & DL_DMASK) + TAP_W(t) == d) && (!live || (v & DL_LIVE));
-                if (ok) code = t | (live ? 0 : 8);
-            }
-        }
-    }
-    par[fo + p] = (u8)code;
-    }
-}
-
-// k_exit: one block per 128 x 128 tile of parent codes.  Inside the tile the chains are resolved by
-// pointer doubling in LDS (every cell does the same work each round: no divergent walks, and the number
-// of rounds is log2 of the longest in-tile chain, whatever the distances are).  A cell is terminal if it
-// is a source, has no parent, or its parent lies outside the tile.  Result per pixel: an exit pointer
+// k_exit: one block per 128 x 128 tile.  Loads the tile of dl (d | live<<15) with a 2-cell halo into LDS,
+// applies the 5x5 parent rule there, and resolves the chains inside the tile by pointer doubling in LDS
+// (every cell does the same work each round: no divergent walks, and the number of rounds is log2 of the
+// longest in-tile chain, whatever the distances are).  A cell is terminal if it is a source, has no
+// parent, or its parent lies outside the tile.  Result per pixel: an exit pointer
 //   bit 31 set : the chain's root source, pixel index in the low bits
 //   0x7FFFFFFF : no source in the frame
 //   otherwise  : pixel index (another tile) where the chain continues
+// Also stores the float distance map (the last consumer of d).
 constexpr int X_T = 128;             // tile edge
+constexpr int X_P = X_T + 4;         // dl tile pitch (2-cell halo each side)
 constexpr u32 X_ROOT = 0x80000000u;  // exit pointer: resolved to a root
 constexpr u32 X_NONE = 0x7FFFFFFFu;  // exit pointer: frame without sources
+constexpr int X_BORDER = 0x3FF0;     // dl value outside the image: (v & mask) + w never equals a d | live<<15
 
-__global__ __launch_bounds__(256) void k_exit(const u8 *__restrict__ par, const int *__restrict__ fflag, int H,
-                                              int W, int tiles_x, u32 *__restrict__ exitp) {
+__global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const int *__restrict__ fflag, int H,
+                                              int W, int tiles_x, u32 *__restrict__ exitp,
+                                              float *__restrict__ out_dt) {
+    __shared__ __attribute__((aligned(16))) u16 s_big[X_P * X_P];  // dl tile + halo; later the pointers (X_T*X_T)
     __shared__ u8 s_code[X_T * X_T];
-    __shared__ u16 s_ptr[X_T * X_T];
     const int b = blockIdx.y;
     if (!fflag[b]) return;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * X_T, c0 = tx * X_T;
     const size_t fo = (size_t)b * H * W;
-    const u8 *parf = par + fo;
+    const u16 *dlf = dl + fo;
     const int tid = threadIdx.x;
 
+    for (int k = tid; k < X_P * X_P; k += 256) {
+        const int r = k / X_P, c = k - r * X_P;
+        const int gi = r0 + r - 2, gj = c0 + c - 2;
+        s_big[k] = (gi >= 0 && gi < H && gj >= 0 && gj < W) ? dlf[(size_t)gi * W + gj] : (u16)X_BORDER;
+    }
+    __syncthreads();
+    // parent rule, straight-line: tap t forward for live cells, the negated tap for the others; keep the
+    // code format of tap_decode (t | backward << 3)
     for (int k = tid; k < X_T * X_T; k += 256) {
         const int r = k >> 7, c = k & (X_T - 1);
-        const int gi = r0 + r, gj = c0 + c;
-        const int code = (gi < H && gj < W) ? (int)parf[(size_t)gi * W + gj] : PAR_NONE;
+        const u16 *p = s_big + (r + 2) * X_P + c + 2;
+        const int v = *p;
+        const int d = v & DL_DMASK;
+        const int live = v >> 15;
+        const int sgn = live ? 1 : -1;
+        const int msk = live ? 0xFFFF : DL_DMASK;
+        int t_sel = -1;
+#pragma unroll
+        for (int t = 7; t >= 0; --t) {  // descending: the FIRST matching tap is kept
+            const int nv = p[sgn * (TAP_DI(t) * X_P + TAP_DJ(t))];
+            t_sel = ((nv & msk) + TAP_W(t) == v) ? t : t_sel;
+        }
+        int code = t_sel < 0 ? PAR_NONE : (t_sel | (live ? 0 : 8));
+        code = d == DL_NONE ? PAR_NONE : code;
+        code = d == 0 ? PAR_SRC : code;
         s_code[k] = (u8)code;
+        const int gi = r0 + r, gj = c0 + c;
+        if (out_dt && gi < H && gj < W)
+            out_dt[fo + (size_t)gi * W + gj] = d == DL_NONE ? 8192.0f : (float)d;  // float(INIT_DIST0 * 2^-16) == 8192.0f
+    }
+    __syncthreads();
+    u16 *s_ptr = s_big;  // the dl tile is dead
+    for (int k = tid; k < X_T * X_T; k += 256) {
+        const int r = k >> 7, c = k & (X_T - 1);
+        const int code = s_code[k];
         int di, dj;
         tap_decode(code, di, dj);
         const int nr = r + di, nc = c + dj;
@@ -924,11 +942,11 @@ __global__ __launch_bounds__(256) void k_exit(const u8 *__restrict__ par, const 
 
 // k_final: follow the exit pointers from tile to tile (a chain crosses few tiles), then label, gather, store.
 __global__ __launch_bounds__(256) void k_final(
-    const float *__restrict__ x, const u16 *__restrict__ dl, const u32 *__restrict__ exitp,
+    const float *__restrict__ x, const u32 *__restrict__ exitp,
     const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
     const int *__restrict__ finfo, const float *__restrict__ vlist, const int *__restrict__ fflag, int H,
-    int W, int Wd, float *__restrict__ out_depth, float *__restrict__ out_dt,
-    int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
+    int W, int Wd, float *__restrict__ out_depth, int32_t *__restrict__ out_index,
+    int *__restrict__ frame_status) {
     const int b = blockIdx.y;
     if (!fflag[b]) return;
     const size_t fo = (size_t)b * H * W;
@@ -944,10 +962,6 @@ __global__ __launch_bounds__(256) void k_final(
             label = source_rank(rowbase_s[(size_t)b * H + i] + wpre_s[w], srcbits[w], j);
         }
         if (out_index) out_index[fo + p] = label;
-        if (out_dt) {
-            const int d = dl[fo + p] & DL_DMASK;
-            out_dt[fo + p] = d == DL_NONE ? 8192.0f : (float)d;  // float(INIT_DIST0 * 2^-16) == 8192.0f
-        }
         if (out_depth)
             out_depth[fo + p] = gather_depth(x + fo, vlist + fo, label, q, finfo[b * FI_STRIDE + FI_NVAL],
                                              finfo[b * FI_STRIDE + FI_MISALIGNED], frame_status + b);
@@ -961,7 +975,6 @@ inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 struct Carve {
     u16 *gu, *g, *dB, *dl;
-    u8 *par;
     u32 *exitp;
     u64 *srcbits, *valbits;
     u16 *wpre_s, *wpre_v;
@@ -1001,7 +1014,6 @@ Carve carve(void *ws, int B, int H, int W) {
     c.g = (u16 *)take(N * 2);
     c.dB = (u16 *)take(N * 2);
     c.dl = (u16 *)take(N * 2);
-    c.par = (u8 *)take(N);
     c.exitp = (u32 *)take(N * 4);
     c.vlist = (float *)take(N * 4);
     c.total = off;
@@ -1013,9 +1025,9 @@ bool shape_ok(int B, int H, int W) {
            (long long)B * H * W < (1ll << 31);
 }
 
-constexpr int NK_L1 = 9;
-const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame",   "k_fused",  "k_colscan", "k_skew",
-                                     "k_rowscan", "k_parent", "k_exit",   "k_final"};
+constexpr int NK_L1 = 8;
+const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame",   "k_fused", "k_colscan",
+                                     "k_skew", "k_rowscan", "k_exit",  "k_final"};
 
 int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, float *out_depth,
            float *out_dt, int32_t *out_index, int32_t *frame_status, void *workspace, unsigned flags,
@@ -1072,19 +1084,17 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag2, H,
                                                                               W, ngroups, c.dl);
         mark();
-        k_parent<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(c.dl, c.fflag2, H, W, c.par);
-        mark();
         {
             const int etx = (W + X_T - 1) / X_T, ety = (H + X_T - 1) / X_T;
-            k_exit<<<dim3(etx * ety, B), 256, 0, st>>>(c.par, c.fflag2, H, W, etx, c.exitp);
+            k_exit<<<dim3(etx * ety, B), 256, 0, st>>>(c.dl, c.fflag2, H, W, etx, c.exitp, out_dt);
         }
         mark();
         k_final<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(
-            x, c.dl, c.exitp, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, c.fflag2, H, W, Wd, out_depth,
-            out_dt, out_index, status);
+            x, c.exitp, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, c.fflag2, H, W, Wd, out_depth, out_index,
+            status);
         mark();
     } else {
-        for (int t = 0; t < 6; ++t) mark();
+        for (int t = 0; t < 5; ++t) mark();
     }
     return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
