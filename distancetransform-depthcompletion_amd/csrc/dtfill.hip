@@ -660,12 +660,15 @@ constexpr int G_NCH = 16;  // row chunks (= waves per block) of the chunked colu
 //   pass A: last / first source row of every column inside the chunk -> LDS
 //   pass B: carry in the nearest source row above / below the chunk, then
 //           down sweep: gu(i,j) = rows to the nearest source at or above (i,j);  up sweep: g = min(gu, gd).
+// L2 = true (the `l2` metric): g carries in bit 15 whether that nearest source is BELOW the pixel (strictly
+// nearer than the one above: on a vertical tie the upper source has the smaller raster index).
+template <bool L2>
 __global__ __launch_bounds__(64 * G_NCH) void k_colscan(const u64 *__restrict__ srcbits,
                                                         const int *__restrict__ fflag, int H, int W, int Wd,
                                                         int CR, u16 *__restrict__ gu, u16 *__restrict__ g) {
     __shared__ int s_last[G_NCH][64], s_first[G_NCH][64];
     const int b = blockIdx.y, wd = blockIdx.x, lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
-    if (!fflag[b]) return;
+    if (fflag && !fflag[b]) return;
     const int j = wd * 64 + lane;
     const bool inb = j < W;
     const size_t fo = (size_t)b * H * W;
@@ -702,9 +705,71 @@ __global__ __launch_bounds__(64 * G_NCH) void k_colscan(const u64 *__restrict__ 
         dn = s ? 0 : min(dn + 1, BIG);
         if (inb) {
             const int u = ld16(guf + (size_t)i * W + j);
-            gf[(size_t)i * W + j] = st16(min(u, dn));
+            if (L2) {
+                const int m = min(u, dn);
+                gf[(size_t)i * W + j] = m >= 0x7FFF ? (u16)INF16 : (u16)(m | (dn < u ? 0x8000 : 0));
+            } else {
+                gf[(size_t)i * W + j] = st16(min(u, dn));
+            }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// l2 metric: k_l2row.  One lane per pixel.  With g(i,k) the vertical distance to the nearest source of
+// column k, the exact squared Euclidean distance is min_k g(i,k)^2 + (j-k)^2; the columns are visited
+// outward from j (r = |j-k| = 0,1,2,...) and the search stops once r^2 exceeds the best value, so the
+// work per pixel is ~2 sqrt(d^2) candidates.  Ties go to the smallest raster index of the SOURCE
+// (smaller row, then smaller column) -- the order brute force gives.  Then rank -> label, gather, store.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_l2row(const float *__restrict__ x, const u16 *__restrict__ g,
+                                               const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
+                                               const u32 *__restrict__ rowbase_s, const int *__restrict__ finfo,
+                                               const float *__restrict__ vlist, int H, int W, int Wd,
+                                               float *__restrict__ out_depth, float *__restrict__ out_dt,
+                                               int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const size_t fo = (size_t)b * H * W;
+    const int i = p / W, j = p - i * W;
+    const u16 *grow = g + fo + (size_t)i * W;
+    // best candidate: key = (d2, source row, source column), lexicographic
+    long long best = 0x7FFFFFFFFFFFFFFFll;
+    int bestd2 = 0x7FFFFFFF;
+    const int rmax = finfo[b * FI_STRIDE + FI_NSRC] ? W : 0;  // a frame without sources has nothing to search
+    for (int r = 0; r < rmax; ++r) {
+        if ((long long)r * r > bestd2) break;  // r*r == bestd2 still matters: a same-row source ties on d2
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int k = side ? j + r : j - r;
+            if (k < 0 || k >= W || (side && r == 0)) continue;
+            const int v = grow[k];
+            if (v == INF16) continue;
+            const int gv = v & 0x7FFF;
+            const int srow = (v & 0x8000) ? i + gv : i - gv;
+            const int d2 = gv * gv + r * r;
+            const long long key = ((long long)d2 << 32) | ((long long)srow << 16) | k;
+            if (key < best) {
+                best = key;
+                bestd2 = d2;
+            }
+        }
+    }
+    int label = 0, q = p;
+    float dist = INFINITY;
+    if (bestd2 != 0x7FFFFFFF) {
+        const int srow = (int)((best >> 16) & 0xFFFF), scol = (int)(best & 0xFFFF);
+        q = srow * W + scol;
+        const size_t w = ((size_t)b * H + srow) * Wd + (scol >> 6);
+        label = source_rank(rowbase_s[(size_t)b * H + srow] + wpre_s[w], srcbits[w], scol);
+        dist = sqrtf((float)bestd2);
+    }
+    if (out_index) out_index[fo + p] = label;
+    if (out_dt) out_dt[fo + p] = dist;
+    if (out_depth)
+        out_depth[fo + p] = gather_depth(x + fo, vlist + fo, label, q, finfo[b * FI_STRIDE + FI_NVAL],
+                                         finfo[b * FI_STRIDE + FI_MISALIGNED], frame_status + b);
 }
 
 // k_skew: knight lines u = j + 2 i over the extended column range j in [0, W] (column W is virtual:
@@ -1073,7 +1138,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     }
     mark();
     if (!fused_only) {
-        k_colscan<<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, c.fflag2, H, W, Wd, (H + G_NCH - 1) / G_NCH, c.gu, c.g);
+        k_colscan<false><<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, c.fflag2, H, W, Wd, (H + G_NCH - 1) / G_NCH, c.gu, c.g);
         mark();
         const int nU = W + 2 * (H - 1) + 1;
         k_skew<<<dim3((nU + 63) / 64, B), 64 * G_NCH, 0, st>>>(c.gu, c.fflag2, H, W, c.dB);
@@ -1099,11 +1164,38 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
 
+constexpr int NK_L2 = 4;
+const char *const kNamesL2[NK_L2] = {"k_mask", "k_frame", "k_colscan", "k_l2row"};
+
+int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, float *out_depth, float *out_dt,
+           int32_t *out_index, int32_t *frame_status, void *workspace, hipStream_t st, hipEvent_t *ev) {
+    const Carve c = carve(workspace, B, H, W);
+    const int Wd = (W + 63) / 64;
+    int *status = frame_status ? frame_status : c.status;
+    int k = 0;
+    auto mark = [&]() {
+        if (ev) (void)hipEventRecord(ev[k++], st);
+    };
+    mark();
+    k_mask<<<dim3((H + 4 * M_RPW - 1) / (4 * M_RPW), B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits,
+                                                                      c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v);
+    mark();
+    k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
+                               c.finfo, c.vlist, c.fflag, c.fflag2, status, 0);
+    mark();
+    k_colscan<true><<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, nullptr, H, W, Wd, (H + G_NCH - 1) / G_NCH, c.gu, c.g);
+    mark();
+    k_l2row<<<dim3((H * W + 255) / 256, B), 256, 0, st>>>(x, c.g, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W,
+                                                         Wd, out_depth, out_dt, out_index, status);
+    mark();
+    return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
+}
+
 int check_args(const float *x, int B, int H, int W, int metric, float *out_depth, float *out_dt,
                int32_t *out_index, void *workspace, size_t ws_bytes) {
     if (!x || !workspace || (!out_depth && !out_dt && !out_index)) return DTFILL_ERR_NULL;
     if (!shape_ok(B, H, W)) return DTFILL_ERR_SHAPE;
-    if (metric != DTFILL_METRIC_L1_CV) return DTFILL_ERR_METRIC;
+    if (metric != DTFILL_METRIC_L1_CV && metric != DTFILL_METRIC_L2) return DTFILL_ERR_METRIC;
     if (ws_bytes < dtfill_workspace_bytes(B, H, W, metric) || ((uintptr_t)workspace & 255))
         return DTFILL_ERR_WORKSPACE;
     return DTFILL_OK;
@@ -1130,7 +1222,7 @@ const char *dtfill_strerror(int code) {
 
 size_t dtfill_workspace_bytes(int B, int H, int W, int metric) {
     if (!shape_ok(B, H, W)) return 0;
-    if (metric != DTFILL_METRIC_L1_CV) return 0;
+    if (metric != DTFILL_METRIC_L1_CV && metric != DTFILL_METRIC_L2) return 0;
     return carve(nullptr, B, H, W).total;
 }
 
@@ -1139,6 +1231,9 @@ int dtfill_batch_flags(const float *x, int B, int H, int W, float src_thr, float
                        void *workspace, size_t ws_bytes, void *stream, unsigned flags) {
     int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes);
     if (rc != DTFILL_OK) return rc;
+    if (metric == DTFILL_METRIC_L2)
+        return run_l2(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace,
+                      static_cast<hipStream_t>(stream), nullptr);
     return run_l1(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags,
                   static_cast<hipStream_t>(stream), nullptr);
 }
@@ -1150,10 +1245,13 @@ int dtfill_batch(const float *x, int B, int H, int W, float src_thr, float val_t
                               frame_status, workspace, ws_bytes, stream, 0u);
 }
 
-int dtfill_num_kernels(int metric) { return metric == DTFILL_METRIC_L1_CV ? NK_L1 : 0; }
+int dtfill_num_kernels(int metric) {
+    return metric == DTFILL_METRIC_L1_CV ? NK_L1 : metric == DTFILL_METRIC_L2 ? NK_L2 : 0;
+}
 
 const char *dtfill_kernel_name(int metric, int k) {
     if (metric == DTFILL_METRIC_L1_CV && k >= 0 && k < NK_L1) return kNamesL1[k];
+    if (metric == DTFILL_METRIC_L2 && k >= 0 && k < NK_L2) return kNamesL2[k];
     return "";
 }
 
@@ -1164,14 +1262,17 @@ int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float
     if (rc != DTFILL_OK) return rc;
     if (!kernel_ms) return DTFILL_ERR_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nk = dtfill_num_kernels(metric);
     hipEvent_t ev[NK_L1 + 1];
-    for (int k = 0; k <= NK_L1; ++k)
+    for (int k = 0; k <= nk; ++k)
         if (hipEventCreate(&ev[k]) != hipSuccess) return DTFILL_ERR_NO_DEVICE;
-    rc = run_l1(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags,
-                st, ev);
-    (void)hipEventSynchronize(ev[NK_L1]);
-    for (int k = 0; k < NK_L1; ++k) (void)hipEventElapsedTime(&kernel_ms[k], ev[k], ev[k + 1]);
-    for (int k = 0; k <= NK_L1; ++k) (void)hipEventDestroy(ev[k]);
+    rc = metric == DTFILL_METRIC_L2
+             ? run_l2(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, st, ev)
+             : run_l1(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags, st,
+                      ev);
+    (void)hipEventSynchronize(ev[nk]);
+    for (int k = 0; k < nk; ++k) (void)hipEventElapsedTime(&kernel_ms[k], ev[k], ev[k + 1]);
+    for (int k = 0; k <= nk; ++k) (void)hipEventDestroy(ev[k]);
     return rc;
 }
 

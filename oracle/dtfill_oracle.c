@@ -205,6 +205,60 @@ int oracle_fill_batch(const float *x, int B, int H, int W, float src_thr, float 
     return bad;
 }
 
+/* ---- the `l2` mode: exact Euclidean transform + the same value-list glue --------------------------
+ * out_dt = sqrtf(squared distance) (+inf without sources); out_idx = 1-based raster rank of the nearest
+ * source, ties -> smallest raster index (0 without sources); out_depth = depth_list[idx-1] with the
+ * numpy index semantics of tools.py:26.  There is no reference code for this mode (the reference is
+ * L1 only); BASELINE.json's north_star asks for it, brute force (brute_nearest) defines it.          */
+void edt_l2_labels(const uint8_t *mask, int H, int W, int32_t *dist2, int32_t *near);
+#include <math.h>
+int oracle_fill_frame_l2(const float *x, int H, int W, float src_thr, float val_thr,
+                         float *out_depth, float *out_dt, int32_t *out_idx)
+{
+    size_t n = (size_t)H * W, p, nval = 0;
+    uint8_t *mask = (uint8_t *)malloc(n);
+    int32_t *d2 = (int32_t *)malloc(n * sizeof(int32_t));
+    int32_t *near = (int32_t *)malloc(n * sizeof(int32_t));
+    int32_t *rank = (int32_t *)malloc(n * sizeof(int32_t));
+    float *vlist = (float *)malloc(n * sizeof(float) + 4);
+    int rc = ORACLE_OK, k = 0;
+    for (p = 0; p < n; p++) {
+        volatile float one_minus = 1.0f - x[p];
+        mask[p] = (one_minus > src_thr) ? 1 : 0;
+        rank[p] = mask[p] ? 0 : ++k;
+        if (x[p] > val_thr)
+            vlist[nval++] = x[p];
+    }
+    edt_l2_labels(mask, H, W, d2, near);
+    for (p = 0; p < n; p++) {
+        int32_t lbl = near[p] < 0 ? 0 : rank[near[p]];
+        long long idx = (long long)lbl - 1;
+        if (out_idx) out_idx[p] = lbl;
+        if (out_dt) out_dt[p] = near[p] < 0 ? INFINITY : sqrtf((float)d2[p]);
+        if (idx < 0) idx += (long long)nval;
+        if (idx < 0 || idx >= (long long)nval)
+            rc = ORACLE_INDEX_ERROR;
+        else if (out_depth)
+            out_depth[p] = vlist[idx];
+    }
+    free(mask); free(d2); free(near); free(rank); free(vlist);
+    return rc;
+}
+
+int oracle_fill_batch_l2(const float *x, int B, int H, int W, float src_thr, float val_thr,
+                         float *out_depth, float *out_dt, int32_t *out_idx, int32_t *status)
+{
+    size_t n = (size_t)H * W;
+    int b, bad = 0;
+    for (b = 0; b < B; b++) {
+        int rc = oracle_fill_frame_l2(x + b * n, H, W, src_thr, val_thr, out_depth ? out_depth + b * n : NULL,
+                                      out_dt ? out_dt + b * n : NULL, out_idx ? out_idx + b * n : NULL);
+        if (status) status[b] = rc;
+        bad += rc != ORACLE_OK;
+    }
+    return bad;
+}
+
 /* ---- brute force nearest source, tiny frames only (O(N*K)) ----------------------------------
  * metric 1 = L1, 2 = squared L2.  Tie-break: smallest raster index of the source (canonical).
  * dist2: int32 distance (L1) or squared distance (L2); INT_MAX where no source exists.

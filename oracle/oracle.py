@@ -43,6 +43,8 @@ def lib():
         L.oracle_fill_frame.restype = ci
         L.oracle_fill_batch.argtypes = [vp, ci, ci, ci, cf, cf, vp, vp, vp, vp]
         L.oracle_fill_batch.restype = ci
+        L.oracle_fill_batch_l2.argtypes = [vp, ci, ci, ci, cf, cf, vp, vp, vp, vp]
+        L.oracle_fill_batch_l2.restype = ci
         L.brute_nearest.argtypes = [vp, ci, ci, ci, vp, vp]
         L.brute_nearest.restype = None
         L.edt_l2_labels.argtypes = [vp, ci, ci, vp, vp]
@@ -105,16 +107,18 @@ def Distance_Transform(lidar, src_thr=0.001, val_thr=0.1):
     return np.reshape(depth_list_all, (height, width))
 
 
-def fill_batch(x, src_thr=0.1, val_thr=0.1):
+def fill_batch(x, src_thr=0.1, val_thr=0.1, metric="l1_cv"):
     """All-C batched path (used for bulk parity and the cpu_baseline timing).
-    x: float32 [B,H,W].  Returns depth, dt, index(int32 labels), status(int32 [B])."""
+    x: float32 [B,H,W].  Returns depth, dt, index(int32 labels), status(int32 [B]).
+    metric "l1_cv" = the reference's cv2 transform; "l2" = exact Euclidean, canonical tie-break."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     B, H, W = x.shape
     depth = np.empty_like(x)
     dt = np.empty_like(x)
     idx = np.empty(x.shape, np.int32)
     status = np.zeros(B, np.int32)
-    lib().oracle_fill_batch(_p(x), B, H, W, src_thr, val_thr, _p(depth), _p(dt), _p(idx), _p(status))
+    fn = lib().oracle_fill_batch if metric == "l1_cv" else lib().oracle_fill_batch_l2
+    fn(_p(x), B, H, W, src_thr, val_thr, _p(depth), _p(dt), _p(idx), _p(status))
     return depth, dt, idx, status
 
 

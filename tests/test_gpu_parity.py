@@ -237,6 +237,63 @@ def test_tile_seams_and_halo_boundary(gpu_op, oracle):
     assert_equal_to_oracle(oracle, gpu_op, x)  # 1.2 %: a mix of decided and flagged frames
 
 
+def test_l2_metric_vs_oracle(pkg, oracle):
+    """The `l2` mode (exact Euclidean transform, ties -> smallest raster index of the source):
+    index map and squared distances bit-exact (the float distance is sqrtf of an exact integer,
+    compared at rtol 1e-6, inside the 1e-5 BASELINE.json's north_star allows), depth gathered
+    through the same value-list glue."""
+    import torch
+
+    op = pkg.device.DtFill(device="cuda:0", metric="l2")
+    rng = np.random.default_rng(77)
+    frames = []
+    for t in range(12):
+        B, H, W = int(rng.integers(1, 3)), int(rng.integers(1, 120)), int(rng.integers(1, 300))
+        p = rng.choice([0.002, 0.02, 0.05, 0.4])
+        x = np.where(rng.random((B, H, W)) < p, rng.uniform(0.95, 80, (B, H, W)), 0).astype(np.float32)
+        if t == 3:
+            x[:] = 0  # no source at all
+        if t == 4:
+            x[0, 0, :3] = [0.5, 0.3, 0.85]  # values that are not sources: misaligned enumerations
+        frames.append(x)
+    lat = np.zeros((1, 60, 90), np.float32)
+    lat[0, ::10, ::10] = 3.0  # lattice: every kind of tie
+    frames.append(lat)
+    for x in frames:
+        depth, dt, idx, status = oracle.fill_batch(x, metric="l2")
+        res = op.run(torch.from_numpy(x).to("cuda:0"))
+        torch.cuda.synchronize()
+        got = {k: v.cpu().numpy() for k, v in res.items()}
+        assert np.array_equal(got["index"], idx), "l2 index map differs: %d px" % (got["index"] != idx).sum()
+        assert np.allclose(got["dt"], dt, rtol=1e-6, atol=0), "l2 distance differs"
+        assert np.array_equal(np.isinf(got["dt"]), np.isinf(dt))
+        assert np.array_equal(got["status"] & 1, status)
+        ok = status == 0
+        assert np.array_equal(got["depth"][ok], depth[ok], equal_nan=True)
+
+
+def test_l2_full_size_properties(pkg, oracle):
+    """KITTI-size batch in l2 mode: the index is a true Euclidean-nearest source (checked against
+    the exact transform of a few frames) and one full frame equals the oracle."""
+    import torch
+
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    op = pkg.device.DtFill(device="cuda:0", metric="l2")
+    x = synth.make("kitti_b32", B=4)
+    res = op.run(torch.from_numpy(x).to("cuda:0"))
+    torch.cuda.synchronize()
+    idx = res["index"].cpu().numpy()
+    dt = res["dt"].cpu().numpy()
+    depth, dt0, idx0, _ = oracle.fill_batch(x[:1], metric="l2")
+    assert np.array_equal(idx[0], idx0[0]) and np.allclose(dt[0], dt0[0], rtol=1e-6)
+    assert np.array_equal(res["depth"].cpu().numpy()[0], depth[0])
+    ii, jj = np.indices(x.shape[1:])
+    for b in range(1, 4):
+        pos = np.argwhere(x[b] >= 0.9)
+        d2 = (ii - pos[idx[b] - 1, 0]) ** 2 + (jj - pos[idx[b] - 1, 1]) ** 2
+        assert np.allclose(np.sqrt(d2.astype(np.float32)), dt[b], rtol=1e-6)
+
+
 def test_shape_errors(gpu_op, pkg):
     import torch
 

@@ -100,6 +100,28 @@ def test_l2_oracle_against_bruteforce(oracle):
         assert np.array_equal(d0, d1) and np.array_equal(n0, n1)
 
 
+def test_l2_fill_against_scipy_edt(oracle):
+    """The l2 fill oracle against scipy's exact Euclidean transform: equal distances; the chosen
+    source is at that distance (indices are compared modulo ties -- the canonical tie-break itself
+    is pinned by brute force in test_l2_oracle_against_bruteforce)."""
+    ndimage = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(5)
+    x = np.where(rng.random((3, 50, 70)) < 0.04, rng.uniform(1, 80, (3, 50, 70)), 0).astype(np.float32)
+    depth, dt, idx, status = oracle.fill_batch(x, metric="l2")
+    ii, jj = np.indices(x.shape[1:])
+    for b in range(3):
+        src = x[b] >= 0.9
+        e = ndimage.distance_transform_edt(~src)
+        assert np.allclose(dt[b], e, rtol=1e-6)
+        pos = np.argwhere(src)
+        d2 = (ii - pos[idx[b] - 1, 0]) ** 2 + (jj - pos[idx[b] - 1, 1]) ** 2
+        assert np.array_equal(d2, np.round(e ** 2).astype(np.int64))
+        assert np.array_equal(depth[b], x[b][pos[idx[b] - 1, 0], pos[idx[b] - 1, 1]])
+    empty = np.zeros((1, 4, 5), np.float32)
+    depth, dt, idx, status = oracle.fill_batch(empty, metric="l2")
+    assert np.isinf(dt).all() and (idx == 0).all() and status[0] == 1
+
+
 def test_real_cv2_if_present(oracle):
     """Opportunistic pin: on a machine that has OpenCV, the restatement must equal it."""
     cv2 = pytest.importorskip("cv2")
