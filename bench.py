@@ -40,7 +40,15 @@ def cpu_baseline(x, budget_s=12.0):
     from oracle import oracle as O
 
     O.lib()
-    cores = os.cpu_count() or 1
+    # threads = the CPUs this process may actually use (affinity / cgroup quota), not every core of the host
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, 64)
     B = x.shape[0]
     t0 = time.perf_counter()
     O.fill_batch(x[:1])
@@ -67,6 +75,8 @@ def main():
     ap.add_argument("--workload", default="kitti_b32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path", default="auto", choices=["auto", "general", "fused"])
+    ap.add_argument("--metric", default="l1_cv", choices=["l1_cv", "l2"],
+                    help="l1_cv = the reference's cv2 transform (headline); l2 = exact Euclidean")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,7 +96,7 @@ def main():
 
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
-    op = pkg.device.DtFill(device=dev)
+    op = pkg.device.DtFill(device=dev, metric=args.metric)
 
     cfg = synth.CONFIGS[args.workload]
     xh = synth.make(args.workload, B=args.batch, seed=cfg["kwargs"]["seed"] + rank)
@@ -152,7 +162,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s: B=%d frames/GPU of %dx%d, %s" % (args.workload, B, H, W, json.dumps(cfg["kwargs"])),
-                "metric_mode": "l1_cv", "outputs": "depth+dt+index", "frames_per_gpu": B,
+                "metric_mode": args.metric, "outputs": "depth+dt+index", "frames_per_gpu": B,
                 "parallelism": "frame-sharded x%d, no collective" % world,
             },
             "roofline": {
@@ -166,7 +176,7 @@ def main():
             "frames_with_index_error": status_bad,
             "frames_on_general_path": general_frames,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.metric == "l1_cv":
             line["cpu_baseline"] = cpu_baseline(xh)
         print(json.dumps(line))
     if dist is not None:

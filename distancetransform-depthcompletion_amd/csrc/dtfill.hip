@@ -27,19 +27,23 @@
 // (chain length <= d(q) hops).
 //
 // Locality: everything that decides label(q) lies inside the L1 ball of radius d(q) around q.  So a
-// tile plus a halo of FR pixels, held in LDS, gives the exact result for every tile pixel with
+// tile plus a halo of FR pixels, held on chip, gives the exact result for every tile pixel with
 // d <= FR, and detects (d > FR) the ones it cannot decide.
 //
-// Kernels of one pass:
+// Kernels of one l1_cv pass:
 //   k_mask     source / value bit words (ballots) + per-row prefix popcounts       reads x once
 //   k_frame    per-frame row-count scan -> compaction ranks; frame facts; value list when the source
 //              and value masks of a frame differ (else depth_list[lbl-1] == x at the source pixel)
-//   k_fused    one workgroup per (tile + halo) window, all of it in LDS: column scans, row scans,
-//              knight-line scan, 5x5 parent rule, chain walk, rank lookup, depth gather, and the
-//              three output stores.  Flags the frame if any tile pixel has d > FR.
-//   general path (only frames flagged by k_fused; blocks of other frames exit at once):
-//   k_colscan, k_skew, k_rowscan, k_parent, k_resolve -- the same mathematics with full-frame scans
-//              through HBM, valid for any distance.
+//   k_fused<16>  one workgroup per (tile + halo 16) window, bit-sliced: the level-synchronous form of
+//              the identity above on bit planes held in registers (one lane per window row, taps as word
+//              shifts), byte codes un-sliced into LDS, lock-step chain walk, rank lookup, depth gather
+//              and the three output stores.  Flags the frame if any tile pixel has d > 16.
+//   k_fused<32>  the same with halo 32, only for frames the first stage flagged.
+//   general path (only frames k_fused<32> flagged too; blocks of other frames exit at once):
+//   k_colscan, k_skew, k_rowscan  full-frame column / knight-line / row scans through HBM (uint16)
+//   k_exit     5x5 parent rule + in-tile chain resolution by pointer doubling in LDS -> exit pointers
+//   k_final    follows the few tile-to-tile hops, rank -> label, gather, store.      Any distance.
+// l2 pass (exact Euclidean, canonical tie-break): k_mask, k_frame, k_colscan<true>, k_l2row.
 //
 // No MFMA anywhere: this path is compare/min/index work (DESIGN.md "Roofline").
 

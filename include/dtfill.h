@@ -37,7 +37,8 @@ extern "C" {
 
 /* metric */
 #define DTFILL_METRIC_L1_CV 0 /* reference parity: OpenCV L1 5x5 chamfer + its label tie-break order */
-#define DTFILL_METRIC_L2    1 /* exact Euclidean transform, tie-break = smallest raster index */
+#define DTFILL_METRIC_L2    1 /* exact Euclidean transform, tie-break = smallest raster index of the source
+                                 (not in the reference, which is L1 only; BASELINE.json's north_star asks for it) */
 
 /* return codes */
 #define DTFILL_OK               0
@@ -54,12 +55,12 @@ extern "C" {
                                        a label addresses past the value list, or label 0 (no source in
                                        the frame) with an empty value list.  out_depth of that frame is
                                        then unspecified; out_dt / out_index are still exact. */
-#define DTFILL_FRAME_GENERAL_PATH 2 /* informational: the frame held a pixel farther than the LDS tile
-                                       halo from every source and was computed by the full-frame
-                                       (any-distance) kernels; results are identical either way. */
+#define DTFILL_FRAME_GENERAL_PATH 2 /* informational (l1_cv): the frame held a pixel farther than 32 pixels
+                                       from every source and was computed by the full-frame (any-distance)
+                                       kernels instead of the LDS tile kernels; results are identical. */
 
 /* flags of dtfill_batch_flags(): path selection, for tests and benchmarks */
-#define DTFILL_FLAG_GENERAL_ONLY 1u /* skip the fused tile kernel, every frame takes the general path */
+#define DTFILL_FLAG_GENERAL_ONLY 1u /* skip the fused tile kernels, every frame takes the general path */
 #define DTFILL_FLAG_FUSED_ONLY   2u /* skip the general kernels: frames that need them are left
                                        undefined and carry DTFILL_FRAME_GENERAL_PATH in their status */
 
