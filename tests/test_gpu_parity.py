@@ -294,6 +294,46 @@ def test_l2_full_size_properties(pkg, oracle):
         assert np.allclose(np.sqrt(d2.astype(np.float32)), dt[b], rtol=1e-6)
 
 
+def test_extreme_shapes_vs_oracle(gpu_op, oracle):
+    """Shapes that stress the index arithmetic: rows wider than 4096 pixels (more than 64 bit words
+    per row), tall thin frames, the largest supported H+W, and a batch with many small frames."""
+    rng = np.random.default_rng(31)
+    for B, H, W, p in [(1, 3, 5000, 0.01), (1, 5000, 3, 0.01), (1, 40, 8150, 0.002), (1, 8100, 90, 0.002),
+                       (70, 17, 23, 0.1), (2, 129, 4097, 0.03)]:
+        x = np.where(rng.random((B, H, W)) < p, rng.uniform(0.95, 80, (B, H, W)), 0).astype(np.float32)
+        assert_equal_to_oracle(oracle, gpu_op, x)
+    # one source in a corner of the largest frame: distances up to H + W - 2 = 8189
+    x = np.zeros((1, 100, 8091), np.float32)
+    x[0, 99, 8090] = 2.0
+    assert_equal_to_oracle(oracle, gpu_op, x, paths=("auto",))
+
+
+def test_random_fuzz_both_metrics(pkg, gpu_op, oracle):
+    """Seeded fuzz over shapes, densities, thresholds and structured holes (both metrics)."""
+    import torch
+
+    op2 = pkg.device.DtFill(device="cuda:0", metric="l2")
+    rng = np.random.default_rng(4242)
+    for t in range(25):
+        B, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 200)), int(rng.integers(1, 400))
+        p = float(rng.choice([0.001, 0.01, 0.05, 0.2, 0.7]))
+        lo = float(rng.choice([0.05, 0.5, 0.95]))
+        x = np.where(rng.random((B, H, W)) < p, rng.uniform(lo, 80, (B, H, W)), 0).astype(np.float32)
+        if t % 3 == 0:
+            r0, r1 = sorted(rng.integers(0, H + 1, 2))
+            x[:, r0:r1] = 0
+        if t % 4 == 0:
+            c0, c1 = sorted(rng.integers(0, W + 1, 2))
+            x[:, :, c0:c1] = 0
+        st, vt = (0.001, 0.1) if t % 5 == 0 else (0.1, 0.1)
+        assert_equal_to_oracle(oracle, gpu_op, x, st, vt)
+        depth, dt, idx, status = oracle.fill_batch(x, st, vt, metric="l2")
+        res = op2.run(torch.from_numpy(x).to("cuda:0"), st, vt)
+        torch.cuda.synchronize()
+        assert np.array_equal(res["index"].cpu().numpy(), idx)
+        assert np.allclose(res["dt"].cpu().numpy(), dt, rtol=1e-6, atol=0)
+
+
 def test_shape_errors(gpu_op, pkg):
     import torch
 
