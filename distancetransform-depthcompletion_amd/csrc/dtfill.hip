@@ -319,34 +319,39 @@ __device__ __forceinline__ float gather_depth(const float *__restrict__ xf, cons
 // lock-step; d is |drow| + |dcol| to the root.
 // LDS: 25.3 KB ring/s_par + 6 KB bit words and ranks.
 // ------------------------------------------------------------------------------------------------
-constexpr int F_WHM = 128;  // window rows = lanes of two waves
+constexpr int F_WHM = 128;  // window rows
 constexpr int F_WWM = 192;  // window columns = 6 words
-constexpr int F_NT = 128;
+constexpr int F_NT = 256;   // lane = (row, half): waves 0-1 own words 0..2 of rows 0..127, waves 2-3 words 3..5
 constexpr int F_P = 196;               // s_par row pitch: 49 dwords (odd) -> lane-per-row dword stores are conflict-free
 constexpr int F_NWD = 6;               // 32-bit words per window row
+constexpr int F_HW = 3;                // words per lane
+constexpr int F_RS = 7;                // ring row stride in words: 6 + one zero pad (odd: conflict-free; the pad is
+                                       // also the zero "word -1" of the next row and "word 6" of this one)
 constexpr int F_RROWS = F_WHM + 4;     // ring rows: 2 zero rows above and below the window
+constexpr int F_RPLANE = F_RROWS * F_RS;
+constexpr int F_RING = 1 + 4 * 2 * F_RPLANE;  // one leading zero word, then [slot][plane E/L][row][7]
 constexpr int F_EB = 8;                // tile pixels per lane walked in lock-step
 // byte code of a source: 0x80 | 18 = step (0,0)
 constexpr int F_NONE = 0xC0 | 18;      // byte code of an undecided pixel: also step (0,0), plus bit 6
 static_assert(F_WWM == 32 * F_NWD, "window width must be six words");
-static_assert(4 * 2 * F_RROWS * F_NWD * 4 >= F_WHM * F_P, "s_par must fit in the ring's memory");
+static_assert(F_RING * 4 >= F_WHM * F_P, "s_par must fit in the ring's memory");
 
 #define ENC_F(t) (((TAP_DI(t) + 2) << 3) | (TAP_DJ(t) + 2))
 
-// word i of the row shifted so that result[c] = row[c + DJ]
+// a[0..4] = the lane's three words a[1..3] with their left / right neighbour words; word i (0..2) of the
+// row shifted so that result[c] = row[c + DJ]
 template <int DJ>
-__device__ __forceinline__ u32 hshift(const u32 (&w)[F_NWD], int i) {
-    const u32 lo = i > 0 ? w[i - 1] : 0u, me = w[i], hi = i < F_NWD - 1 ? w[i + 1] : 0u;
-    if (DJ == 0) return me;
-    if (DJ > 0) return __builtin_amdgcn_alignbit(hi, me, DJ);
-    return __builtin_amdgcn_alignbit(me, lo, 32 + DJ);
+__device__ __forceinline__ u32 hshift(const u32 (&a)[5], int i) {
+    if (DJ == 0) return a[i + 1];
+    if (DJ > 0) return __builtin_amdgcn_alignbit(a[i + 2], a[i + 1], DJ);
+    return __builtin_amdgcn_alignbit(a[i + 1], a[i], 32 + DJ);
 }
 
 // one tap of the first-match chain: cand = shift(src, DJ); winners get the bits of ENC in the code planes
 template <int DJ, int ENC>
-__device__ __forceinline__ void tap_step(const u32 (&src)[F_NWD], u32 (&taken)[F_NWD], u32 (&C)[6][F_NWD]) {
+__device__ __forceinline__ void tap_step(const u32 (&src)[5], u32 (&taken)[F_HW], u32 (&C)[6][F_HW]) {
 #pragma unroll
-    for (int i = 0; i < F_NWD; ++i) {
+    for (int i = 0; i < F_HW; ++i) {
         const u32 cand = hshift<DJ>(src, i);
         const u32 sel = cand & ~taken[i];
         taken[i] |= cand;
@@ -356,19 +361,18 @@ __device__ __forceinline__ void tap_step(const u32 (&src)[F_NWD], u32 (&taken)[F
     }
 }
 
-__device__ __forceinline__ void ring_load(const u32 *__restrict__ ring, int slot, int plane, int row, u32 (&w)[F_NWD]) {
-    const uint2 *p = reinterpret_cast<const uint2 *>(ring + ((slot * 2 + plane) * F_RROWS + row) * F_NWD);
+// the lane's three words of a ring row plus one neighbour word on each side (pads / other half)
+__device__ __forceinline__ void ring_load5(const u32 *__restrict__ ring, int slot, int plane, int row, int wb,
+                                           u32 (&a)[5]) {
+    const u32 *p = ring + 1 + (slot * 2 + plane) * F_RPLANE + row * F_RS + wb - 1;
 #pragma unroll
-    for (int i = 0; i < F_NWD / 2; ++i) {
-        const uint2 v = p[i];
-        w[2 * i] = v.x;
-        w[2 * i + 1] = v.y;
-    }
+    for (int i = 0; i < 5; ++i) a[i] = p[i];
 }
-__device__ __forceinline__ void ring_store(u32 *__restrict__ ring, int slot, int plane, int row, const u32 (&w)[F_NWD]) {
-    uint2 *p = reinterpret_cast<uint2 *>(ring + ((slot * 2 + plane) * F_RROWS + row) * F_NWD);
+__device__ __forceinline__ void ring_store3(u32 *__restrict__ ring, int slot, int plane, int row, int wb,
+                                            const u32 (&w)[F_HW]) {
+    u32 *p = ring + 1 + (slot * 2 + plane) * F_RPLANE + row * F_RS + wb;
 #pragma unroll
-    for (int i = 0; i < F_NWD / 2; ++i) p[i] = make_uint2(w[2 * i], w[2 * i + 1]);
+    for (int i = 0; i < F_HW; ++i) p[i] = w[i];
 }
 
 // FR = halo = largest distance the window can decide.  gate (nullable): only frames with gate[b] != 0
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(F_NT) void k_fused(
             return;
         }
     }
-    __shared__ __attribute__((aligned(16))) u32 s_ring[4 * 2 * F_RROWS * F_NWD];  // later: s_par bytes
+    __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
     __shared__ u32 s_sb[F_WHM * 8];  // source bits of the window rows, image-aligned 64-pixel words (as u32 pairs)
     __shared__ u32 s_rk[F_WHM * 4];  // sources before each of those 64-pixel words (frame raster order)
 
@@ -413,138 +417,152 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     const int w0 = wc0 >> 6;                             // first image word column the window touches (-1 if wc0 < 0)
     const int sh = wc0 - 64 * w0;                        // window column 0 is bit sh of image word w0
 
-    // ---- P0: this lane's row: image-aligned words -> LDS (for the ranks), window-aligned planes -> registers
-    const int r = tid;  // window row of this lane
-    u32 M[F_NWD], D[F_NWD];
+    // ---- P0: this lane's half row: image-aligned words -> LDS (for the ranks), window-aligned planes -> registers
+    const int r = tid & (F_WHM - 1);  // window row of this lane
+    const int hf = tid >> 7;          // which half of the row (wave-uniform)
+    const int wb = F_HW * hf;         // first of the lane's three words
+    u32 M[F_HW], D[F_HW];
     {
         const int gi = wr0 + r;
         const bool rowin = r < WH && gi >= 0 && gi < H;
-        u32 g[10];
+        // the lane's 96 window columns start at bit sh + 96 hf of the row's image-aligned bit string;
+        // three image words (192 bits) starting at word (sh + 96 hf) / 64 cover them
+        const int bit0 = sh + 96 * hf;
+        const int kw = bit0 >> 6;  // wave-uniform
+        u32 g[7];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int w = w0 + k;
+        for (int k = 0; k < 3; ++k) {
+            const int kk = kw + k;  // 0..3 relative to w0
+            const int w = w0 + kk;
             u64 sb = 0;
             u32 rk = 0;
-            if (rowin && w >= 0 && w < Wd) {
+            if (rowin && kk < 4 && w >= 0 && w < Wd) {
                 const size_t wi = ((size_t)b * H + gi) * Wd + w;
                 sb = srcbits[wi];
                 rk = rowbase_s[(size_t)b * H + gi] + wpre_s[wi];
             }
             g[2 * k] = (u32)sb;
             g[2 * k + 1] = (u32)(sb >> 32);
-            s_sb[r * 8 + 2 * k] = g[2 * k];
-            s_sb[r * 8 + 2 * k + 1] = g[2 * k + 1];
-            s_rk[r * 4 + k] = rk;
+            // each of the four image words of a row is stored once: half 0 stores its words kk = 0, 1 (and 2
+            // if half 1 starts later), half 1 the rest
+            const bool mine = hf == 0 ? kk < 2 : (kk >= 2 && kk < 4);
+            if (mine) {
+                s_sb[r * 8 + 2 * kk] = g[2 * k];
+                s_sb[r * 8 + 2 * kk + 1] = g[2 * k + 1];
+                s_rk[r * 4 + kk] = rk;
+            }
         }
-        g[8] = g[9] = 0;
-        const bool hi = sh & 32;  // block-uniform
-        const int s5 = sh & 31;
+        g[6] = 0;
+        const int s6 = bit0 & 63;
+        const bool hi = s6 & 32;  // wave-uniform
+        const int s5 = s6 & 31;
 #pragma unroll
-        for (int i = 0; i < F_NWD; ++i) {
+        for (int i = 0; i < F_HW; ++i) {
             const u32 lo_w = hi ? g[i + 1] : g[i], hi_w = hi ? g[i + 2] : g[i + 1];
             const u32 word = s5 ? __builtin_amdgcn_alignbit(hi_w, lo_w, s5) : lo_w;
-            // in-image columns of this word: [max(ca, 32 i), min(cb, 32 i + 32))
-            const int lo = max(ca - 32 * i, 0), up = min(cb - 32 * i, 32);
+            // in-image columns of window word wb + i: [max(ca, 32 (wb+i)), min(cb, 32 (wb+i) + 32))
+            const int lo = max(ca - 32 * (wb + i), 0), up = min(cb - 32 * (wb + i), 32);
             u32 m = 0;
             if (rowin && up > lo) m = (up >= 32 ? 0xFFFFFFFFu : ((1u << up) - 1u)) & ~((1u << lo) - 1u);
             M[i] = m;
             D[i] = word & m;
         }
     }
-    // level 0: E_0 = L_0 = sources; zero the rest of the ring (levels "-1,-2,-3" and the guard rows)
-    for (int k = tid; k < 4 * 2 * F_RROWS * F_NWD; k += F_NT) s_ring[k] = 0;
+    // level 0: E_0 = L_0 = sources; zero the rest of the ring (levels "-1,-2,-3", the guard rows, the pads)
+    for (int k = tid; k < F_RING; k += F_NT) s_ring[k] = 0;
     __syncthreads();
-    ring_store(s_ring, 0, 0, r + 2, D);
-    ring_store(s_ring, 0, 1, r + 2, D);
-    u32 C[6][F_NWD];
+    ring_store3(s_ring, 0, 0, r + 2, wb, D);
+    ring_store3(s_ring, 0, 1, r + 2, wb, D);
+    u32 C[6][F_HW];
 #pragma unroll
     for (int j = 0; j < 6; ++j)
 #pragma unroll
-        for (int i = 0; i < F_NWD; ++i) C[j][i] = ((18 >> j) & 1) ? D[i] : 0u;  // sources: enc 18
-    u32 Dup[F_NWD], Ddn[F_NWD], Eprev[F_NWD], Lprev[F_NWD];
+        for (int i = 0; i < F_HW; ++i) C[j][i] = ((18 >> j) & 1) ? D[i] : 0u;  // sources: enc 18
+    u32 Dup[F_HW], Ddn[F_HW];
+    u32 Dl = 0, Dr = 0;  // D's neighbour words left / right of the lane's three (other half or nothing)
 #pragma unroll
-    for (int i = 0; i < F_NWD; ++i) {
-        Dup[i] = Ddn[i] = 0;
-        Eprev[i] = Lprev[i] = D[i];
-    }
+    for (int i = 0; i < F_HW; ++i) Dup[i] = Ddn[i] = 0;
     __syncthreads();
     if (stop_after == 0) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
     // ---- P1: levels
     for (int t = 1; t <= FR; ++t) {
         const int s1 = (t - 1) & 3, s2 = (t - 2) & 3, s3 = (t - 3) & 3, sw = t & 3;
-        u32 nb[F_NWD], taken[F_NWD], Et[F_NWD], Lt[F_NWD];
-        // dilation of D_{t-1}: left/right in registers, up/down through the rows r-1 / r+1 of E_{t-1}
-        ring_load(s_ring, s1, 0, r + 1, nb);
+        u32 nb[5], e1[5], l1[5], taken[F_HW], Et[F_HW], Lt[F_HW];
+        // dilation of D_{t-1}: left/right in registers (+ the neighbour words), up/down through E_{t-1}
+        ring_load5(s_ring, s1, 0, r + 2, wb, e1);  // E_{t-1}, this row (also the last tap's source)
+        Dl |= e1[0];
+        Dr |= e1[4];
+        ring_load5(s_ring, s1, 0, r + 1, wb, nb);  // E_{t-1}, row r-1
 #pragma unroll
-        for (int i = 0; i < F_NWD; ++i) Dup[i] |= nb[i];
-        u32 E1d[F_NWD];
-        ring_load(s_ring, s1, 0, r + 3, E1d);
+        for (int i = 0; i < F_HW; ++i) Dup[i] |= nb[i + 1];
+        u32 e1d[5];
+        ring_load5(s_ring, s1, 0, r + 3, wb, e1d);  // E_{t-1}, row r+1
         bool nonempty = false;
+        {
+            const u32 dd[5] = {Dl, D[0], D[1], D[2], Dr};
 #pragma unroll
-        for (int i = 0; i < F_NWD; ++i) {
-            Ddn[i] |= E1d[i];
-            const u32 dil = hshift<1>(D, i) | hshift<-1>(D, i) | Dup[i] | Ddn[i];
-            Et[i] = dil & ~D[i] & M[i];
-            taken[i] = ~Et[i];
-            nonempty |= Et[i] != 0;
+            for (int i = 0; i < F_HW; ++i) {
+                Ddn[i] |= e1d[i + 1];
+                const u32 dil = hshift<1>(dd, i) | hshift<-1>(dd, i) | Dup[i] | Ddn[i];
+                Et[i] = dil & ~D[i] & M[i];
+                taken[i] = ~Et[i];
+                nonempty |= Et[i] != 0;
+            }
         }
         // forward taps in cv2 order; the candidates are live pixels of levels t-3, t-2, t-1
-        ring_load(s_ring, s3, 1, r + 0, nb);  // L_{t-3}, row r-2
+        ring_load5(s_ring, s3, 1, r + 0, wb, nb);  // L_{t-3}, row r-2
         tap_step<-1, ENC_F(0)>(nb, taken, C);
         tap_step<1, ENC_F(1)>(nb, taken, C);
         {
-            u32 l3[F_NWD], l2[F_NWD], l1[F_NWD];
-            ring_load(s_ring, s3, 1, r + 1, l3);  // L_{t-3}, row r-1
-            ring_load(s_ring, s2, 1, r + 1, l2);  // L_{t-2}, row r-1
-            ring_load(s_ring, s1, 1, r + 1, l1);  // L_{t-1}, row r-1
+            u32 l3[5], l2[5];
+            ring_load5(s_ring, s3, 1, r + 1, wb, l3);  // L_{t-3}, row r-1
+            ring_load5(s_ring, s2, 1, r + 1, wb, l2);  // L_{t-2}, row r-1
+            ring_load5(s_ring, s1, 1, r + 1, wb, nb);  // L_{t-1}, row r-1
             tap_step<-2, ENC_F(2)>(l3, taken, C);
             tap_step<-1, ENC_F(3)>(l2, taken, C);
-            tap_step<0, ENC_F(4)>(l1, taken, C);
+            tap_step<0, ENC_F(4)>(nb, taken, C);
             tap_step<1, ENC_F(5)>(l2, taken, C);
             tap_step<2, ENC_F(6)>(l3, taken, C);
         }
-        tap_step<-1, ENC_F(7)>(Lprev, taken, C);
+        ring_load5(s_ring, s1, 1, r + 2, wb, l1);  // L_{t-1}, this row
+        tap_step<-1, ENC_F(7)>(l1, taken, C);
 #pragma unroll
-        for (int i = 0; i < F_NWD; ++i) {
+        for (int i = 0; i < F_HW; ++i) {
             Lt[i] = taken[i] & Et[i];
             taken[i] = ~(Et[i] & ~Lt[i]);  // backward chain only for the non-live pixels of E_t
         }
         // backward taps (negated offsets, same order); candidates are ALL pixels of levels t-3, t-2, t-1
-        ring_load(s_ring, s3, 0, r + 4, nb);  // E_{t-3}, row r+2
+        ring_load5(s_ring, s3, 0, r + 4, wb, nb);  // E_{t-3}, row r+2
         tap_step<1, 36 - ENC_F(0)>(nb, taken, C);
         tap_step<-1, 36 - ENC_F(1)>(nb, taken, C);
         {
-            u32 e3[F_NWD], e2[F_NWD];
-            ring_load(s_ring, s3, 0, r + 3, e3);  // E_{t-3}, row r+1
-            ring_load(s_ring, s2, 0, r + 3, e2);  // E_{t-2}, row r+1
+            u32 e3[5], e2[5];
+            ring_load5(s_ring, s3, 0, r + 3, wb, e3);  // E_{t-3}, row r+1
+            ring_load5(s_ring, s2, 0, r + 3, wb, e2);  // E_{t-2}, row r+1
             tap_step<2, 36 - ENC_F(2)>(e3, taken, C);
             tap_step<1, 36 - ENC_F(3)>(e2, taken, C);
-            tap_step<0, 36 - ENC_F(4)>(E1d, taken, C);
+            tap_step<0, 36 - ENC_F(4)>(e1d, taken, C);
             tap_step<-1, 36 - ENC_F(5)>(e2, taken, C);
             tap_step<-2, 36 - ENC_F(6)>(e3, taken, C);
         }
-        tap_step<1, 36 - ENC_F(7)>(Eprev, taken, C);
+        tap_step<1, 36 - ENC_F(7)>(e1, taken, C);
 #pragma unroll
-        for (int i = 0; i < F_NWD; ++i) {
-            D[i] |= Et[i];
-            Eprev[i] = Et[i];
-            Lprev[i] = Lt[i];
-        }
-        ring_store(s_ring, sw, 0, r + 2, Et);
-        ring_store(s_ring, sw, 1, r + 2, Lt);
+        for (int i = 0; i < F_HW; ++i) D[i] |= Et[i];
+        ring_store3(s_ring, sw, 0, r + 2, wb, Et);
+        ring_store3(s_ring, sw, 1, r + 2, wb, Lt);
         if (!__syncthreads_or(nonempty)) break;  // nothing at distance t anywhere: nothing farther either
     }
     if (stop_after == 1) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
-    // ---- P2: un-slice the code planes of this row into bytes, 4 pixels per step.
+    // ---- P2: un-slice the code planes of this half row into bytes, 4 pixels per step.
     // ((nibble * 0x00204081) & 0x01010101) spreads bits 0..3 of the nibble to the low bits of 4 bytes.
     u8 *s_par = reinterpret_cast<u8 *>(s_ring);
     __syncthreads();  // the ring is dead for everybody before its memory becomes s_par
     {
-        u32 *prow = reinterpret_cast<u32 *>(s_par + r * F_P);
+        u32 *prow = reinterpret_cast<u32 *>(s_par + r * F_P) + wb * 8;
 #pragma unroll
-        for (int i = 0; i < F_NWD; ++i) {
+        for (int i = 0; i < F_HW; ++i) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 u32 v = 0x80808080u;
