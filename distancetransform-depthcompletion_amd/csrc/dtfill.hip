@@ -101,7 +101,8 @@ __device__ __forceinline__ u16 st16(int v) { return (u16)(v >= INF16 ? INF16 : v
 // (1 = fill, 0 = source); value predicate as tools.py:22, x > thr.  Per 64-pixel word: the two bit
 // words and the row-local exclusive popcount; per row: totals (+ "masks differ" in bit 31).
 // ------------------------------------------------------------------------------------------------
-constexpr int M_RPW = 4;  // image rows per wave in k_mask (independent loads in flight)
+constexpr int M_RPW = 1;  // image rows per wave in k_mask
+constexpr int M_KU = 8;   // 64-pixel steps whose loads are issued together (M_KU * M_RPW loads in flight per lane)
 
 __device__ __forceinline__ u32 wave_incl_sum(u32 v, int lane) {
 #pragma unroll
@@ -130,21 +131,28 @@ __global__ __launch_bounds__(256) void k_mask(const float *__restrict__ x, int H
         u64 ws[M_RPW], wv[M_RPW];
 #pragma unroll
         for (int q = 0; q < M_RPW; ++q) ws[q] = wv[q] = 0;
-#pragma unroll 2
-        for (int k = 0; k < nk; ++k) {
-            const int j = (k0 + k) * 64 + lane;
-            float v[M_RPW];
+        for (int kb = 0; kb < nk; kb += M_KU) {  // M_KU word steps x M_RPW rows: all loads first, then the ballots
+            float v[M_KU][M_RPW];
 #pragma unroll
-            for (int q = 0; q < M_RPW; ++q) {
-                const int i = min(i0 + q, H - 1);
-                v[q] = j < W ? x[((size_t)b * H + i) * W + j] : 0.0f;
+            for (int u = 0; u < M_KU; ++u) {
+                const int j = (k0 + kb + u) * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < M_RPW; ++q) {
+                    const int i = min(i0 + q, H - 1);
+                    v[u][q] = (kb + u < nk && j < W) ? x[((size_t)b * H + i) * W + j] : 0.0f;
+                }
             }
 #pragma unroll
-            for (int q = 0; q < M_RPW; ++q) {
-                const u64 sb = __ballot(j < W && !((1.0f - v[q]) > src_thr));
-                const u64 vb = __ballot(j < W && (v[q] > val_thr));
-                ws[q] = lane == k ? sb : ws[q];
-                wv[q] = lane == k ? vb : wv[q];
+            for (int u = 0; u < M_KU; ++u) {
+                const int k = kb + u;
+                const bool in = k < nk && (k0 + k) * 64 + lane < W;
+#pragma unroll
+                for (int q = 0; q < M_RPW; ++q) {
+                    const u64 sb = __ballot(in && !((1.0f - v[u][q]) > src_thr));
+                    const u64 vb = __ballot(in && (v[u][q] > val_thr));
+                    ws[q] = lane == k ? sb : ws[q];
+                    wv[q] = lane == k ? vb : wv[q];
+                }
             }
         }
 #pragma unroll
