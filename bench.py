@@ -88,8 +88,16 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one rank per GPU over RCCL.  DTFILL_BENCH_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs
+        # than ranks (the ranks then share devices and the barrier / max run over gloo on the host).
+        backend = os.environ.get("DTFILL_BENCH_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        assert backend == "gloo" or local_rank < ndev, "rank %d has no GPU (%d visible)" % (local_rank, ndev)
+        torch.cuda.set_device(local_rank % ndev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -117,7 +125,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
