@@ -863,69 +863,114 @@ __global__ __launch_bounds__(64 * G_NCH) void k_skew(const u16 *__restrict__ gu,
     for (int i = c0; i < c1; ++i) D = skew_step(guf, dBf, W, nU, u, i, D);
 }
 
-// k_rowscan: one wave per image row.  d(i,j) = min_k g(i,k) + |j-k| as prefix-min of (g-k) plus
-// suffix-min of (g+k); dA as prefix-min of (gu-k).  64-pixel groups are scanned with wave shuffles,
-// the group-to-group carry is a wave-uniform scalar.
-__device__ __forceinline__ int wave_prefix_min(int v, int lane) {
+// k_rowscan: one wave per image row, 8 consecutive pixels per lane (one 16-byte load per array), 512
+// pixels per segment.  With a(j) = min_{k<=j} g(k) + (j-k) and dA likewise from gu (left-to-right), then
+// d(j) = min_{k>=j} a(k) + (k-j) over a itself (right-to-left; a <= g and a(k)+(k-j) is a real path length,
+// so this equals the two-sided minimum over g):  live = (dA == d) or (dB == d).
+// Inside a lane the scans are sequential (8 steps); across lanes ONE wave scan of the lane totals per
+// segment and quantity; across segments a wave-uniform carry.  The left-to-right results wait in a
+// per-wave LDS row buffer.
+__device__ __forceinline__ int wave_excl_prefix_min(int v, int lane) {  // min over lanes < lane (BIG for lane 0)
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(v, off);
+        const int t = __shfl_up(v, off);
         if (lane >= off) v = min(v, t);
     }
-    return v;
+    const int e = __shfl_up(v, 1);
+    return lane == 0 ? BIG : e;
 }
-__device__ __forceinline__ int wave_suffix_min(int v, int lane) {
+__device__ __forceinline__ int wave_excl_suffix_min(int v, int lane) {  // min over lanes > lane (BIG for lane 63)
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_down(v, off);
+        const int t = __shfl_down(v, off);
         if (lane + off < 64) v = min(v, t);
     }
-    return v;
+    const int e = __shfl_down(v, 1);
+    return lane == 63 ? BIG : e;
+}
+
+// 8 consecutive uint16 of a row starting at element idx0 (multiple of 8); vectorised when the row is 16-byte aligned
+__device__ __forceinline__ void load8(const u16 *__restrict__ row, int idx0, int W, bool vec, int (&v)[8]) {
+    if (vec && idx0 + 8 <= W) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(row + idx0);
+        v[0] = q.x & 0xFFFF; v[1] = q.x >> 16; v[2] = q.y & 0xFFFF; v[3] = q.y >> 16;
+        v[4] = q.z & 0xFFFF; v[5] = q.z >> 16; v[6] = q.w & 0xFFFF; v[7] = q.w >> 16;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = idx0 + q < W ? (int)row[idx0 + q] : INF16;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = v[q] == INF16 ? BIG : v[q];
 }
 
 __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, const u16 *__restrict__ gu,
                                                  const u16 *__restrict__ dB, const int *__restrict__ fflag,
-                                                 int H, int W, int ngroups, u16 *__restrict__ dl) {
+                                                 int H, int W, int nseg, u16 *__restrict__ dl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * (blockDim.x >> 6) + wave, b = blockIdx.y;
     if (!fflag[b] || i >= H) return;  // wave-uniform; no block-level barrier below
-    u16 *s_a = reinterpret_cast<u16 *>(smem) + (size_t)wave * ngroups * 128;  // [ngroups*64] a, then dA
-    u16 *s_dA = s_a + ngroups * 64;
+    int *s_a = reinterpret_cast<int *>(smem) + (size_t)wave * nseg * 512;  // a | (dA == a) << 24, lane-private slots
     const size_t ro = ((size_t)b * H + i) * W;
     const u16 *grow = g + ro, *gurow = gu + ro, *dBrow = dB + ro;
+    const bool vec = (W & 7) == 0;  // rows start 16-byte aligned (the arrays are 256-byte aligned)
 
-    int carry_a = BIG, carry_dA = BIG;
-    for (int k = 0; k < ngroups; ++k) {
-        const int idx = k * 64 + lane;
-        const bool in = idx < W;
-        int gv = in ? ld16(grow + idx) : BIG;
-        int guv = in ? ld16(gurow + idx) : BIG;
-        int pa = min(wave_prefix_min(gv - idx, lane), carry_a);
-        int pd = min(wave_prefix_min(guv - idx, lane), carry_dA);
-        carry_a = __shfl(pa, 63);
-        carry_dA = __shfl(pd, 63);
-        s_a[idx] = st16(pa + idx);
-        s_dA[idx] = st16(pd + idx);
+    int carry_a = BIG, carry_dA = BIG;  // min of (value - index) over everything left of the segment
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int idx0 = sg * 512 + lane * 8;
+        int gv[8], uv[8];
+        load8(grow, idx0, W, vec, gv);
+        load8(gurow, idx0, W, vec, uv);
+        int ma = BIG, md = BIG, la[8], ld[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            ma = min(ma, gv[q] - (idx0 + q));
+            md = min(md, uv[q] - (idx0 + q));
+            la[q] = ma;
+            ld[q] = md;
+        }
+        const int ea = min(wave_excl_prefix_min(ma, lane), carry_a);
+        const int ed = min(wave_excl_prefix_min(md, lane), carry_dA);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int a = min(min(la[q], ea) + idx0 + q, BIG);
+            const int dA = min(min(ld[q], ed) + idx0 + q, BIG);
+            s_a[sg * 512 + q * 64 + lane] = a | (dA == a ? 1 << 24 : 0);  // [q][lane]: conflict-free, lane-private
+        }
+        carry_a = __shfl(min(ma, ea), 63);
+        carry_dA = __shfl(min(md, ed), 63);
     }
-    int carry_b = BIG;
-    for (int k = ngroups - 1; k >= 0; --k) {
-        const int idx = k * 64 + lane;
-        const bool in = idx < W;
-        int gv = in ? ld16(grow + idx) : BIG;
-        int sb = min(wave_suffix_min(gv + idx, lane), carry_b);
-        carry_b = __shfl(sb, 0);
-        if (in) {
-            int d = min(ld16(s_a + idx), sb - idx);
-            int out;
-            if (d >= DL_NONE) {
-                out = DL_NONE;  // no source anywhere in the frame
-            } else {
-                int dbv = ld16(dBrow + idx);
-                bool live = (ld16(s_dA + idx) == d) || (dbv == d);
-                out = d | (live ? DL_LIVE : 0);
-            }
-            dl[ro + idx] = (u16)out;
+    int carry_b = BIG;  // min of (a + index) over everything right of the segment
+    for (int sg = nseg - 1; sg >= 0; --sg) {
+        const int idx0 = sg * 512 + lane * 8;
+        int av[8], fl[8], ms = BIG, ls[8];
+#pragma unroll
+        for (int q = 7; q >= 0; --q) {
+            const int v = s_a[sg * 512 + q * 64 + lane];
+            av[q] = v & 0xFFFFFF;
+            fl[q] = v >> 24;
+            ms = min(ms, av[q] + idx0 + q);
+            ls[q] = ms;
+        }
+        const int es = min(wave_excl_suffix_min(ms, lane), carry_b);
+        int dbv[8];
+        load8(dBrow, idx0, W, vec, dbv);
+        u32 out[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int d = min(ls[q], es) - (idx0 + q);
+            const bool live = (fl[q] && av[q] == d) || dbv[q] == d;
+            out[q] = d >= DL_NONE ? (u32)DL_NONE : (u32)(d | (live ? DL_LIVE : 0));  // DL_NONE: no source in the frame
+        }
+        carry_b = __shfl(min(ms, es), 0);
+        if (vec && idx0 + 8 <= W) {
+            uint4 o;
+            o.x = out[0] | out[1] << 16; o.y = out[2] | out[3] << 16; o.z = out[4] | out[5] << 16; o.w = out[6] | out[7] << 16;
+            *reinterpret_cast<uint4 *>(dl + ro + idx0) = o;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (idx0 + q < W) dl[ro + idx0 + q] = (u16)out[q];
         }
     }
 }
@@ -960,10 +1005,18 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
     const u16 *dlf = dl + fo;
     const int tid = threadIdx.x;
 
-    for (int k = tid; k < X_P * X_P; k += 256) {
-        const int r = k / X_P, c = k - r * X_P;
-        const int gi = r0 + r - 2, gj = c0 + c - 2;
-        s_big[k] = (gi >= 0 && gi < H && gj >= 0 && gj < W) ? dlf[(size_t)gi * W + gj] : (u16)X_BORDER;
+    {   // tile + halo, one wave per row, lanes along the row (coalesced, no divisions)
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int r = wave; r < X_P; r += 4) {
+            const int gi = r0 + r - 2;
+            const bool rin = gi >= 0 && gi < H;
+            const u16 *src = dlf + (size_t)(rin ? gi : 0) * W;
+#pragma unroll
+            for (int c = lane; c < X_P; c += 64) {
+                const int gj = c0 + c - 2;
+                s_big[r * X_P + c] = (rin && gj >= 0 && gj < W) ? src[gj] : (u16)X_BORDER;
+            }
+        }
     }
     __syncthreads();
     // parent rule, straight-line: tap t forward for live cells, the negated tap for the others; keep the
@@ -997,8 +1050,8 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
         const int code = s_code[k];
         int di, dj;
         tap_decode(code, di, dj);
-        const int nr = r + di, nc = c + dj;
-        const bool inside = code < 16 && nr >= 0 && nr < X_T && nc >= 0 && nc < X_T;
+        const u32 nr = (u32)(r + di), nc = (u32)(c + dj);
+        const bool inside = code < 16 && nr < (u32)X_T && nc < (u32)X_T;
         s_ptr[k] = inside ? (u16)(nr * X_T + nc) : (u16)(k | 0x8000);
     }
     __syncthreads();
@@ -1173,11 +1226,11 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const int nU = W + 2 * (H - 1) + 1;
         k_skew<<<dim3((nU + 63) / 64, B), 64 * G_NCH, 0, st>>>(c.gu, c.fflag2, H, W, c.dB);
         mark();
-        const int ngroups = Wd;
-        const size_t per_wave = (size_t)ngroups * 128 * sizeof(u16);  // <= 32 KiB at W = 8191
+        const int nseg = (W + 511) / 512;
+        const size_t per_wave = (size_t)nseg * 512 * sizeof(int);  // <= 32 KiB at W = 8191
         const int wpb = (int)max((size_t)1, min((size_t)4, (size_t)65536 / per_wave));
-        k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag2, H,
-                                                                              W, ngroups, c.dl);
+        k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag2, H, W, nseg,
+                                                                              c.dl);
         mark();
         {
             const int etx = (W + X_T - 1) / X_T, ety = (H + X_T - 1) / X_T;
