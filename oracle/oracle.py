@@ -4,8 +4,8 @@ TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and th
 cpu_baseline leg of bench.py, never from the product package.  PARITY UNPINNED: see the
 header of dtfill_oracle.c (cv2 is absent here; the chamfer is restated from OpenCV 3.4).
 
-Reference lines restated here (numpy glue, kept literally so that numpy itself supplies the
-negative-index / IndexError behaviour):
+Reference lines restated here (the glue uses numpy's own fancy indexing, so numpy itself supplies the
+negative-index / IndexError behaviour of the reference):
   nearest_point       solution_DeepNet/tools.py:7-10, eval_NYU.py:114-117
   DT_complete_batch   solution_DeepNet/tools.py:13-35 (demo.py:84-106)
   Distance_Transform  solution_DeepNet/eval_NYU.py:120-133
@@ -68,43 +68,48 @@ def cv_distance_transform_with_labels(mask):
     return dist, lab
 
 
+def _source_mask(frame, src_thr):
+    """uint8 mask handed to the transform: 1 = pixel to fill, 0 = source (tools.py:8, eval_NYU.py:115).
+    Evaluated by numpy in the frame's own dtype, exactly as the reference does."""
+    return np.asarray((1.0 - frame) > src_thr).astype(np.uint8)
+
+
+def _gather_by_label(frame, labels, val_thr):
+    """tools.py:22-27 / eval_NYU.py:124-131: compact the pixels above val_thr in raster order and index
+    that list with label-1.  numpy's own fancy indexing supplies the reference's corner cases: label 0
+    wraps to the last entry, an index past the list raises IndexError."""
+    values = frame[frame > val_thr]
+    picked = values[labels.ravel() - 1]
+    return picked.reshape(frame.shape)
+
+
 def nearest_point(refined_lidar, src_thr=0.1):
-    """tools.py:7-10 (src_thr=0.1) / eval_NYU.py:114-117 (src_thr=0.001)."""
-    value_mask = np.asarray(1.0 - np.squeeze(refined_lidar) > src_thr).astype(np.uint8)
-    dt, lbl = cv_distance_transform_with_labels(value_mask)
-    return dt, lbl
+    """tools.py:7-10 (src_thr=0.1) / eval_NYU.py:114-117 (src_thr=0.001): (dt, lbl) of one frame."""
+    frame = np.squeeze(refined_lidar)
+    return cv_distance_transform_with_labels(_source_mask(frame, src_thr))
 
 
 def DT_complete_batch(lidar_batch, src_thr=0.1, val_thr=0.1):
-    """tools.py:13-35.  The reference hard-codes 352x1216 in its reshapes (tools.py:25,27);
-    H, W are taken from the input here so the same restatement serves every config."""
-    batch_size = np.shape(lidar_batch)[0]
-    new_batch = []
-    for i in range(batch_size):
-        lidar_single = lidar_batch[i, :, :, 0]
-        h, w = np.squeeze(lidar_single).shape
-        dt, lbl = nearest_point(lidar_single, src_thr)
-        with_value = np.squeeze(lidar_single) > val_thr
-        depth_list = np.squeeze(lidar_single)[with_value]
-        label_list = np.reshape(lbl, [1, w * h])
-        depth_list_all = depth_list[label_list - 1]
-        depth_map = np.reshape(depth_list_all, (h, w))
-        new_batch.append(depth_map)
-    new_batch = np.asarray(new_batch)
-    new_batch = np.expand_dims(new_batch, axis=-1)
-    return new_batch.astype(np.float32)
+    """tools.py:13-35: channel 0 of every frame of a [B,H,W,C] batch is filled; float32 [B,H,W,1] back.
+    (The reference hard-codes 352x1216 in its reshapes, tools.py:25,27; H, W come from the input here.)"""
+    filled = []
+    for frame in lidar_batch[..., 0]:
+        frame = np.squeeze(frame)
+        _, labels = nearest_point(frame, src_thr)
+        filled.append(_gather_by_label(frame, labels, val_thr))
+    return np.asarray(filled)[..., np.newaxis].astype(np.float32)
 
 
 def Distance_Transform(lidar, src_thr=0.001, val_thr=0.1):
-    """eval_NYU.py:120-133 (src_thr=0.001 there, 0.1 in the notebooks)."""
-    lidar = np.squeeze(lidar)
-    height, width = np.shape(lidar)
-    with_value = lidar > val_thr
-    dt, lbl = nearest_point(lidar, src_thr)
-    depth_list = np.squeeze(lidar[with_value])
-    label_list = np.reshape(lbl, [1, height * width])
-    depth_list_all = depth_list[label_list - 1]
-    return np.reshape(depth_list_all, (height, width))
+    """eval_NYU.py:120-133 (src_thr=0.001 there, 0.1 in the notebooks): one frame, result in the input's
+    dtype.  eval_NYU.py:125 squeezes the value list, so a frame with exactly ONE value makes it 0-d and the
+    gather on the next line raises IndexError -- reproduced."""
+    frame = np.squeeze(lidar)
+    if frame.ndim != 2:
+        raise ValueError("Distance_Transform expects a frame squeezable to [H,W]")
+    _, labels = nearest_point(frame, src_thr)
+    values = np.squeeze(frame[frame > val_thr])
+    return values[labels.reshape(1, -1) - 1].reshape(frame.shape)
 
 
 def fill_batch(x, src_thr=0.1, val_thr=0.1, metric="l1_cv"):
