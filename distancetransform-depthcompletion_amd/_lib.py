@@ -32,6 +32,7 @@ SYMBOLS = (
     "dtfill_num_kernels",
     "dtfill_kernel_name",
     "dtfill_batch_timed",
+    "dtfill_outlier_removal",
 )
 
 _lib = None
@@ -87,6 +88,8 @@ def load():
     L.dtfill_kernel_name.restype = ctypes.c_char_p
     L.dtfill_batch_timed.argtypes = [vp, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, sz, vp, ctypes.c_uint, vp]
     L.dtfill_batch_timed.restype = ci
+    L.dtfill_outlier_removal.argtypes = [vp, ci, ci, ci, vp, vp]
+    L.dtfill_outlier_removal.restype = ci
     _lib = L
     return L
 

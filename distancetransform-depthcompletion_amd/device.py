@@ -116,6 +116,19 @@ class DtFill:
         return out
 
 
+def outlier_removal_device(x):
+    """x: contiguous float32 CUDA tensor [B,H,W] -> new tensor, data_read.py:103-128 on the device."""
+    _require_gpu()
+    if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 3 or not x.is_contiguous():
+        raise ValueError("x must be a contiguous float32 CUDA tensor [B,H,W]")
+    out = torch.empty_like(x)
+    B, H, W = x.shape
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dtfill_outlier_removal(x.data_ptr(), B, H, W, out.data_ptr(),
+                                                      torch.cuda.current_stream(x.device).cuda_stream))
+    return out
+
+
 _default_ops = {}
 
 

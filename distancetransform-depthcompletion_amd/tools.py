@@ -66,3 +66,16 @@ def Distance_Transform(lidar, src_thr=0.001, val_thr=0.1):
     out = _device.default_op().run_numpy(x[None], src_thr=src_thr, val_thr=val_thr, want=("depth",))
     depth = out["depth"][0]
     return depth.astype(src.dtype) if src.dtype.kind == "f" else depth
+
+
+def outlier_removal(lidar):
+    """data_read.py:103-128 (the loader's optional filter in front of the fill, data_read.py:168-169):
+    zero every pixel that exceeds the mean of the valid pixels in its 7x7 diamond by more than 1.0.
+    Input squeezable to [H,W]; float32 [H,W] back, like the reference."""
+    import torch
+
+    x = np.squeeze(_as_f32_frames(lidar))
+    if x.ndim != 2:
+        raise ValueError("outlier_removal expects an array squeezable to [H,W], got shape %s" % (np.shape(lidar),))
+    xd = torch.from_numpy(np.ascontiguousarray(x[None])).to(_device.default_op().device)
+    return _device.outlier_removal_device(xd)[0].cpu().numpy()

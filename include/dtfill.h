@@ -107,6 +107,15 @@ int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float
                        float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
                        void *workspace, size_t ws_bytes, void *stream, unsigned flags, float *kernel_ms);
 
+/*
+ * outlier_removal() of the reference's loader, data_read.py:103-128 (applied in front of the path when
+ * if_removal=True, data_read.py:168-169): two 7x7-diamond cv2.filter2D sums (values, valid counts;
+ * BORDER_REFLECT_101), out = x where NOT (x - sum/(count + 1e-5) > 1.0), else 0.  The float32 sum is
+ * accumulated over the taps in kernel row-major order, the mean and the test in float64, as
+ * numpy/OpenCV do.  x, out: float32 [B,H,W] device pointers (out may not alias x).  Needs H, W >= 4.
+ */
+int dtfill_outlier_removal(const float *x, int B, int H, int W, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,32 @@ def Distance_Transform(lidar, src_thr=0.001, val_thr=0.1):
     return values[labels.reshape(1, -1) - 1].reshape(frame.shape)
 
 
+_DIAMOND7 = np.array([[abs(i - 3) + abs(j - 3) <= 3 for j in range(7)] for i in range(7)])
+
+
+def outlier_removal(lidar):
+    """data_read.py:103-128 restated (the optional step in front of the path,
+    data_read.py:168-169).  Two cv2.filter2D correlations with the 7x7 diamond of ones (third-party
+    OpenCV again, PARITY UNPINNED): default border BORDER_REFLECT_101; for the float32 frame OpenCV
+    accumulates in float32 over the non-zero kernel taps in kernel row-major order; the valid-pixel
+    count is computed on a float64 image (np.float), so it is exact; mean, difference and the > 1.0 test
+    are float64 by numpy promotion; the result is the frame with the flagged pixels zeroed, float32."""
+    x = np.squeeze(np.asarray(lidar)).astype(np.float32)
+    H, W = x.shape
+    pad = np.pad(x, 3, mode="reflect")  # numpy 'reflect' == BORDER_REFLECT_101
+    acc = np.zeros((H, W), np.float32)
+    cnt = np.zeros((H, W), np.float64)
+    for i in range(7):
+        for j in range(7):
+            if _DIAMOND7[i, j]:
+                win = pad[i : i + H, j : j + W]
+                acc = (acc + win).astype(np.float32)  # sequential float32 accumulation, row-major taps
+                cnt += win > 0.1
+    mean = acc / (cnt + 0.00001)  # float32 / float64 -> float64
+    outlier = (x - mean) > 1.0
+    return np.where(outlier, np.float32(0), x).astype(np.float32)
+
+
 def fill_batch(x, src_thr=0.1, val_thr=0.1, metric="l1_cv"):
     """All-C batched path (used for bulk parity and the cpu_baseline timing).
     x: float32 [B,H,W].  Returns depth, dt, index(int32 labels), status(int32 [B]).

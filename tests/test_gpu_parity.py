@@ -334,6 +334,21 @@ def test_random_fuzz_both_metrics(pkg, gpu_op, oracle):
         assert np.allclose(res["dt"].cpu().numpy(), dt, rtol=1e-6, atol=0)
 
 
+def test_outlier_removal_vs_oracle(pkg, oracle):
+    """data_read.py:103-128.  The result is the input with some pixels zeroed, so parity is
+    exact equality (same float32 accumulation order, float64 decision)."""
+    rng = np.random.default_rng(12)
+    for H, W in [(352, 1216), (7, 9), (4, 4), (33, 130)]:
+        x = np.where(rng.random((H, W)) < 0.3, np.round(rng.uniform(1, 80, (H, W)) * 256) / 256, 0).astype(np.float32)
+        # plant outliers: isolated near values in front of far neighbourhoods and vice versa
+        x[rng.integers(0, H, 40), rng.integers(0, W, 40)] = 75.0
+        got = pkg.outlier_removal(x[None, :, :, None])
+        want = oracle.outlier_removal(x)
+        assert got.dtype == np.float32 and got.shape == (H, W)
+        assert np.array_equal(got, want)
+        assert (want != x).any() or H < 8
+
+
 def test_shape_errors(gpu_op, pkg):
     import torch
 

@@ -122,6 +122,30 @@ def test_l2_fill_against_scipy_edt(oracle):
     assert np.isinf(dt).all() and (idx == 0).all() and status[0] == 1
 
 
+def test_outlier_removal_oracle(oracle):
+    """The restated filter against an independent formulation (scipy.ndimage.correlate, mirror border =
+    BORDER_REFLECT_101) -- float64 there, so only pixels whose decision is not within rounding of the
+    threshold are compared -- and against real cv2 when a machine has it."""
+    ndimage = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(2)
+    x = np.where(rng.random((60, 90)) < 0.3, rng.uniform(1, 80, (60, 90)), 0).astype(np.float32)
+    x[10, 10] = 79.0
+    k = np.array([[abs(i - 3) + abs(j - 3) <= 3 for j in range(7)] for i in range(7)], np.float64)
+    s = ndimage.correlate(x.astype(np.float64), k, mode="mirror")
+    c = ndimage.correlate((x > 0.1).astype(np.float64), k, mode="mirror")
+    margin = x - s / (c + 0.00001) - 1.0
+    want = np.where(margin > 0, 0, x)
+    got = oracle.outlier_removal(x)
+    sure = np.abs(margin) > 1e-3
+    assert np.array_equal(got[sure], want[sure].astype(np.float32)) and (got[10, 10] == 0)
+    try:
+        import cv2
+    except ImportError:
+        return
+    ref = x * (1 - ((x - cv2.filter2D(x, -1, k.astype(np.uint8)) / (cv2.filter2D((x > 0.1).astype(np.float64), -1, k.astype(np.uint8)) + 0.00001)) > 1.0))
+    assert np.array_equal(got, ref.astype(np.float32))
+
+
 def test_real_cv2_if_present(oracle):
     """Opportunistic pin: on a machine that has OpenCV, the restatement must equal it."""
     cv2 = pytest.importorskip("cv2")
