@@ -768,21 +768,33 @@ __global__ __launch_bounds__(256) void k_l2row(const float *__restrict__ x, cons
     long long best = 0x7FFFFFFFFFFFFFFFll;
     int bestd2 = 0x7FFFFFFF;
     const int rmax = finfo[b * FI_STRIDE + FI_NSRC] ? W : 0;  // a frame without sources has nothing to search
-    for (int r = 0; r < rmax; ++r) {
-        if ((long long)r * r > bestd2) break;  // r*r == bestd2 still matters: a same-row source ties on d2
+    constexpr int RC = 4;  // radii per chunk: their 2*RC loads are issued together, then applied in order
+    for (int r0 = 0; r0 < rmax; r0 += RC) {
+        if ((long long)r0 * r0 > bestd2) break;  // r*r == bestd2 still matters: a same-row source ties on d2
+        int v[RC][2];
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int k = side ? j + r : j - r;
-            if (k < 0 || k >= W || (side && r == 0)) continue;
-            const int v = grow[k];
-            if (v == INF16) continue;
-            const int gv = v & 0x7FFF;
-            const int srow = (v & 0x8000) ? i + gv : i - gv;
-            const int d2 = gv * gv + r * r;
-            const long long key = ((long long)d2 << 32) | ((long long)srow << 16) | k;
-            if (key < best) {
-                best = key;
-                bestd2 = d2;
+        for (int u = 0; u < RC; ++u) {
+            const int kl = j - (r0 + u), kr = j + (r0 + u);
+            v[u][0] = kl >= 0 ? (int)grow[kl] : INF16;
+            v[u][1] = (kr < W && r0 + u > 0) ? (int)grow[kr] : INF16;
+        }
+#pragma unroll
+        for (int u = 0; u < RC; ++u) {
+            const int r = r0 + u;
+            if ((long long)r * r > bestd2) break;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int vv = v[u][side];
+                if (vv == INF16) continue;
+                const int k = side ? j + r : j - r;
+                const int gv = vv & 0x7FFF;
+                const int srow = (vv & 0x8000) ? i + gv : i - gv;
+                const int d2 = gv * gv + r * r;
+                const long long key = ((long long)d2 << 32) | ((long long)srow << 16) | k;
+                if (key < best) {
+                    best = key;
+                    bestd2 = d2;
+                }
             }
         }
     }
