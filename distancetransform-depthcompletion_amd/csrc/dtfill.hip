@@ -722,13 +722,43 @@ __global__ __launch_bounds__(64 * G_NCH) void k_colscan(const u64 *__restrict__ 
         below = c > ch ? min(below, s_first[c][lane]) : below;
     }
     int up = min(i0 - 1 - above, BIG);  // value "at row i0-1"
+    int dn = min(below - i1, BIG);      // value "at row i1"
+    if (CR <= 32) {
+        // fast path (H <= 512): the chunk's source bits sit in one register, the from-below distances of its
+        // rows in (statically indexed) registers; one store pass, nothing is re-read
+        u32 bits = 0;
+        for (int i = i0; i < i1; ++i) bits |= (u32)((sbf[(size_t)i * Wd] >> lane) & 1ull) << (i - i0);
+        const int n = i1 - i0;
+        int dnv[32];
+#pragma unroll
+        for (int k = 31; k >= 0; --k) {
+            if (k < n) dn = (bits >> k) & 1u ? 0 : min(dn + 1, BIG);  // rows past the chunk end leave dn at "row i1"
+            dnv[k] = dn;
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (k < n) {
+                up = (bits >> k) & 1u ? 0 : min(up + 1, BIG);
+                if (inb) {
+                    const size_t o = (size_t)(i0 + k) * W + j;
+                    guf[o] = st16(up);
+                    if (L2) {
+                        const int m = min(up, dnv[k]);
+                        gf[o] = m >= 0x7FFF ? (u16)INF16 : (u16)(m | (dnv[k] < up ? 0x8000 : 0));
+                    } else {
+                        gf[o] = st16(min(up, dnv[k]));
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll 4
     for (int i = i0; i < i1; ++i) {
         const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
         up = s ? 0 : min(up + 1, BIG);
         if (inb) guf[(size_t)i * W + j] = st16(up);
     }
-    int dn = min(below - i1, BIG);  // value "at row i1"
 #pragma unroll 4
     for (int i = i1 - 1; i >= i0; --i) {
         const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
