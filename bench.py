@@ -166,7 +166,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32/u16 distances+indices, f32 depth",
+            "dtype": "u32",  # 32-pixel bit planes / byte codes; int32 index, f32 depth + distance only at the stores
             "data": "synthetic",
             "config": {
                 "workload": "%s: B=%d frames/GPU of %dx%d, %s" % (args.workload, B, H, W, json.dumps(cfg["kwargs"])),

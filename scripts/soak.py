@@ -1,0 +1,45 @@
+"""Randomised soak: HIP path (auto + general, and l2) against the oracle on many random frames.
+Usage on the GPU box: python scripts/soak.py [n_cases] [seed]"""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+pkg = importlib.import_module("distancetransform-depthcompletion_amd")
+from oracle import oracle as O
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+op = pkg.device.DtFill(device="cuda:0"); op2 = pkg.device.DtFill(device="cuda:0", metric="l2")
+bad = 0; t0 = time.time(); npx = 0
+for t in range(n):
+    kind = t % 4
+    if kind == 0:   # KITTI-size, densities around the fused halos' limits
+        B, H, W = 2, 352, 1216; p = float(rng.choice([0.008, 0.015, 0.03, 0.05, 0.1]))
+    elif kind == 1:
+        B, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 500)), int(rng.integers(1, 900)); p = float(rng.choice([0.002, 0.02, 0.06, 0.3]))
+    elif kind == 2:  # tile-seam sizes
+        B, H, W = 1, int(rng.choice([87, 88, 89, 95, 96, 97, 176, 192])), int(rng.choice([151, 152, 153, 159, 160, 161, 304, 320])); p = 0.05
+    else:
+        B, H, W = 3, 240, 320; p = float(rng.choice([0.001, 0.005, 0.05]))
+    x = np.where(rng.random((B, H, W)) < p, rng.uniform(0.95, 80, (B, H, W)), 0).astype(np.float32)
+    if rng.random() < 0.4:
+        a, b_ = sorted(rng.integers(0, H + 1, 2)); x[:, a:b_] *= (rng.random((B, 1, 1)) < 0.5)
+    if rng.random() < 0.3:
+        a, b_ = sorted(rng.integers(0, W + 1, 2)); x[:, :, a:b_] = 0
+    depth, dt, lbl, st = O.fill_batch(x)
+    xd = torch.from_numpy(x).cuda()
+    for path in ("auto", "general"):
+        r = op.run(xd, path=path); torch.cuda.synchronize()
+        ok = (np.array_equal(r["dt"].cpu().numpy(), dt) and np.array_equal(r["index"].cpu().numpy(), lbl)
+              and np.array_equal(r["status"].cpu().numpy() & 1, st)
+              and np.array_equal(r["depth"].cpu().numpy()[st == 0], depth[st == 0], equal_nan=True))
+        if not ok:
+            bad += 1; print("MISMATCH case", t, path, (B, H, W), p, "labels differ:", int((r["index"].cpu().numpy() != lbl).sum()))
+    if t % 5 == 0:
+        d2, dt2, idx2, st2 = O.fill_batch(x, metric="l2")
+        r = op2.run(xd); torch.cuda.synchronize()
+        if not (np.array_equal(r["index"].cpu().numpy(), idx2) and np.allclose(r["dt"].cpu().numpy(), dt2, rtol=1e-6, atol=0)):
+            bad += 1; print("L2 MISMATCH case", t, (B, H, W), p)
+    npx += B * H * W
+    if t % 25 == 0: print("case", t, "bad", bad, "%.0fs" % (time.time() - t0), flush=True)
+print("soak done:", n, "cases,", npx, "pixels, mismatches:", bad)
+sys.exit(1 if bad else 0)
