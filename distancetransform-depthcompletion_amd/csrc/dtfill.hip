@@ -1036,7 +1036,7 @@ constexpr int X_BORDER = 0x3FF0;     // dl value outside the image: (v & mask) +
 
 __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const int *__restrict__ fflag, int H,
                                               int W, int tiles_x, u32 *__restrict__ exitp,
-                                              float *__restrict__ out_dt) {
+                                              float *__restrict__ out_dt, int stop_after) {
     __shared__ __attribute__((aligned(16))) u16 s_big[X_P * X_P];  // dl tile + halo; later the pointers (X_T*X_T)
     __shared__ u8 s_code[X_T * X_T];
     const int b = blockIdx.y;
@@ -1047,20 +1047,36 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
     const u16 *dlf = dl + fo;
     const int tid = threadIdx.x;
 
-    {   // tile + halo, one wave per row, lanes along the row (coalesced, no divisions)
+    {   // tile + halo: one wave per row, lanes along the row (coalesced, no divisions); the loads of 8 rows
+        // (24 per lane) are issued before the first LDS store, so the memory round trips overlap
         const int lane = tid & 63, wave = tid >> 6;
-        for (int r = wave; r < X_P; r += 4) {
-            const int gi = r0 + r - 2;
-            const bool rin = gi >= 0 && gi < H;
-            const u16 *src = dlf + (size_t)(rin ? gi : 0) * W;
+        for (int rb = wave; rb < X_P; rb += 4 * 8) {
+            u16 v[8][3];
 #pragma unroll
-            for (int c = lane; c < X_P; c += 64) {
-                const int gj = c0 + c - 2;
-                s_big[r * X_P + c] = (rin && gj >= 0 && gj < W) ? src[gj] : (u16)X_BORDER;
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + 4 * u;
+                const int gi = r0 + r - 2;
+                const bool rin = r < X_P && gi >= 0 && gi < H;
+                const u16 *src = dlf + (size_t)(rin ? gi : 0) * W;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int c = lane + 64 * q, gj = c0 + c - 2;
+                    v[u][q] = (rin && c < X_P && gj >= 0 && gj < W) ? src[gj] : (u16)X_BORDER;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + 4 * u;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int c = lane + 64 * q;
+                    if (r < X_P && c < X_P) s_big[r * X_P + c] = v[u][q];
+                }
             }
         }
     }
     __syncthreads();
+    if (stop_after == 0) return;  // timing-only (DTFILL_EXIT_STOP)
     // parent rule, straight-line: tap t forward for live cells, the negated tap for the others; keep the
     // code format of tap_decode (t | backward << 3)
     for (int k = tid; k < X_T * X_T; k += 256) {
@@ -1086,6 +1102,7 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
             out_dt[fo + (size_t)gi * W + gj] = d == DL_NONE ? 8192.0f : (float)d;  // float(INIT_DIST0 * 2^-16) == 8192.0f
     }
     __syncthreads();
+    if (stop_after == 1) return;
     u16 *s_ptr = s_big;  // the dl tile is dead
     for (int k = tid; k < X_T * X_T; k += 256) {
         const int r = k >> 7, c = k & (X_T - 1);
@@ -1097,6 +1114,7 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
         s_ptr[k] = inside ? (u16)(nr * X_T + nc) : (u16)(k | 0x8000);
     }
     __syncthreads();
+    if (stop_after == 2) return;
     for (int round = 0; round < 16; ++round) {  // 2^16 > any in-tile chain
         bool open = false;
         for (int k = tid; k < X_T * X_T; k += 256) {
@@ -1109,6 +1127,7 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
         }
         if (!__syncthreads_or(open)) break;
     }
+    if (stop_after == 3) return;
     for (int k = tid; k < X_T * X_T; k += 256) {
         const int r = k >> 7, c = k & (X_T - 1);
         const int gi = r0 + r, gj = c0 + c;
@@ -1141,20 +1160,53 @@ __global__ __launch_bounds__(256) void k_final(
     if (!fflag[b]) return;
     const size_t fo = (size_t)b * H * W;
     const u32 *ef = exitp + fo;
-    for (int p = blockIdx.x * (256 * G_PPT) + threadIdx.x, n = 0; n < G_PPT && p < H * W; ++n, p += 256) {
-        u32 e = ef[p];
-        for (int hop = 0; hop < MAX_HW_SUM && !(e & X_ROOT) && e != X_NONE; ++hop) e = ef[e];
-        int label = 0, q = p;
-        if (e & X_ROOT) {
-            q = (int)(e & ~X_ROOT);
-            const int i = q / W, j = q - i * W;
-            const size_t w = ((size_t)b * H + i) * Wd + (j >> 6);
-            label = source_rank(rowbase_s[(size_t)b * H + i] + wpre_s[w], srcbits[w], j);
+    const int N1 = H * W;
+    const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
+    constexpr int FB = 8;  // pixels per lane whose loads are in flight together
+    for (int pb = blockIdx.x * (256 * G_PPT) + threadIdx.x; pb < min(N1, (int)(blockIdx.x + 1) * 256 * G_PPT);
+         pb += 256 * FB) {
+        u32 e[FB];
+#pragma unroll
+        for (int u = 0; u < FB; ++u) e[u] = ef[min(pb + 256 * u, N1 - 1)];
+        for (int hop = 0; hop < MAX_HW_SUM; ++hop) {  // tile-to-tile hops, all FB chains in lock-step
+            bool open = false;
+#pragma unroll
+            for (int u = 0; u < FB; ++u) {
+                const bool mv = !(e[u] & X_ROOT) && e[u] != X_NONE;
+                const u32 nx = ef[mv ? e[u] : 0u];
+                e[u] = mv ? nx : e[u];
+                open |= mv;
+            }
+            if (!__any(open)) break;
         }
-        if (out_index) out_index[fo + p] = label;
-        if (out_depth)
-            out_depth[fo + p] = gather_depth(x + fo, vlist + fo, label, q, finfo[b * FI_STRIDE + FI_NVAL],
-                                             finfo[b * FI_STRIDE + FI_MISALIGNED], frame_status + b);
+        int label[FB], q[FB];
+        u32 base[FB];
+        u64 word[FB];
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+            const bool root = e[u] & X_ROOT;
+            q[u] = root ? (int)(e[u] & ~X_ROOT) : 0;
+            const int i = q[u] / W;
+            const size_t w = ((size_t)b * H + i) * Wd + ((q[u] - i * W) >> 6);
+            base[u] = rowbase_s[(size_t)b * H + i] + wpre_s[w];
+            word[u] = srcbits[w];
+        }
+        float val[FB];
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+            const int i = q[u] / W;
+            label[u] = (e[u] & X_ROOT) ? source_rank(base[u], word[u], q[u] - i * W) : 0;
+            const int p = pb + 256 * u;
+            val[u] = (out_depth && p < N1) ? gather_depth(x + fo, vlist + fo, label[u], q[u], nval, misaligned, frame_status + b)
+                                          : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+            const int p = pb + 256 * u;
+            if (p >= N1) continue;
+            if (out_index) out_index[fo + p] = label[u];
+            if (out_depth) out_depth[fo + p] = val[u];
+        }
     }
 }
 
@@ -1277,6 +1329,8 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     // debug: DTFILL_FUSED_STOP=n makes k_fused return after phase n (timing only, outputs undefined)
     const char *stop_env = ev ? getenv("DTFILL_FUSED_STOP") : nullptr;
     const int fused_stop = stop_env ? atoi(stop_env) : -1;
+    const char *xstop_env = ev ? getenv("DTFILL_EXIT_STOP") : nullptr;
+    const int exit_stop = xstop_env ? atoi(xstop_env) : -1;
     int k = 0;
     auto mark = [&]() {
         if (ev) (void)hipEventRecord(ev[k++], st);
@@ -1322,7 +1376,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         mark();
         {
             const int etx = (W + X_T - 1) / X_T, ety = (H + X_T - 1) / X_T;
-            k_exit<<<dim3(etx * ety, B), 256, 0, st>>>(c.dl, c.fflag2, H, W, etx, c.exitp, out_dt);
+            k_exit<<<dim3(etx * ety, B), 256, 0, st>>>(c.dl, c.fflag2, H, W, etx, c.exitp, out_dt, exit_stop);
         }
         mark();
         k_final<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(
