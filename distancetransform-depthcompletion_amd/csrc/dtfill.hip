@@ -393,21 +393,14 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     float *__restrict__ out_dt, int32_t *__restrict__ out_index, const int *__restrict__ gate,
     int *__restrict__ fflag, int *__restrict__ frame_status, int stop_after) {
     if (gate && !gate[blockIdx.y]) return;
-    {
-        // Speed heuristic only (never correctness): with source density p the chance that a pixel has
-        // no source within L1 distance FR is about (1-p)^(2 FR^2 + 2 FR + 1); if the frame is expected to
-        // hold such a pixel anyway (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), this stage would only
-        // flag the frame after doing all the work -- hand it on right away.  Likewise when k_frame found a run
-        // of source-free rows that forces some distance above FR (real LiDAR frames: the empty sky rows).
-        const long long nsrc = finfo[blockIdx.y * FI_STRIDE + FI_NSRC];
-        if (nsrc * (2 * FR * FR + 2 * FR + 1) < 14ll * H * W || finfo[blockIdx.y * FI_STRIDE + FI_DLB] > FR) {
-            if (threadIdx.x == 0 && blockIdx.x == 0) {
-                fflag[blockIdx.y] = 1;
-                if (FR == 32) atomicOr(frame_status + blockIdx.y, DTFILL_FRAME_GENERAL_PATH);
-            }
-            return;
-        }
-    }
+    // Speed heuristic only (never correctness): with source density p the chance that a pixel has no source
+    // within L1 distance FR is about (1-p)^(2 FR^2 + 2 FR + 1); if the frame is expected to hold such a pixel
+    // anyway (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), this stage would only flag the frame after doing
+    // all the work -- hand it on right away.  Likewise when k_frame found a run of source-free rows that forces
+    // some distance above FR (real LiDAR frames: the empty sky rows).  (The two finfo loads are issued together
+    // with the window loads below; the branch comes after those are in flight.)
+    const long long h_nsrc = finfo[blockIdx.y * FI_STRIDE + FI_NSRC];
+    const int h_dlb = finfo[blockIdx.y * FI_STRIDE + FI_DLB];
     __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
     __shared__ u32 s_sb[F_WHM * 8];  // source bits of the window rows, image-aligned 64-pixel words (as u32 pairs)
     __shared__ u32 s_rk[F_WHM * 4];  // sources before each of those 64-pixel words (frame raster order)
@@ -475,6 +468,13 @@ __global__ __launch_bounds__(F_NT) void k_fused(
             M[i] = m;
             D[i] = word & m;
         }
+    }
+    if (h_nsrc * (2 * FR * FR + 2 * FR + 1) < 14ll * H * W || h_dlb > FR) {  // block-uniform
+        if (threadIdx.x == 0 && blockIdx.x == 0) {
+            fflag[blockIdx.y] = 1;
+            if (FR == 32) atomicOr(frame_status + blockIdx.y, DTFILL_FRAME_GENERAL_PATH);
+        }
+        return;
     }
     // level 0: E_0 = L_0 = sources; zero the rest of the ring (levels "-1,-2,-3", the guard rows, the pads)
     for (int k = tid; k < F_RING; k += F_NT) s_ring[k] = 0;
