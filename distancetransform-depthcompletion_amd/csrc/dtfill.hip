@@ -1115,17 +1115,26 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
     }
     __syncthreads();
     if (stop_after == 2) return;
-    for (int round = 0; round < 16; ++round) {  // 2^16 > any in-tile chain
-        bool open = false;
-        for (int k = tid; k < X_T * X_T; k += 256) {
-            const int p = s_ptr[k];
-            if (!(p & 0x8000)) {
-                const int q = s_ptr[p];  // any value seen here is an ancestor of k: races only speed things up
+    // pointer doubling.  Each thread owns cells tid + 256 j and keeps the still-open ones as bits, so late
+    // rounds only touch what is left; two jumps per round.  Any pointer value read here is an ancestor of the
+    // cell (other threads only ever replace a pointer by a farther ancestor): races just speed things up.
+    {
+        u64 open = 0;
+#pragma unroll 8
+        for (int j = 0; j < X_T * X_T / 256; ++j) open |= (u64)(!(s_ptr[tid + 256 * j] & 0x8000)) << j;
+        for (int round = 0; round < 16; ++round) {  // 4^16 > any in-tile chain
+            u64 m = open;
+            while (m) {
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int k = tid + 256 * j;
+                int q = s_ptr[s_ptr[k]];  // s_ptr[k] has no flag: k is open
+                if (!(q & 0x8000)) q = s_ptr[q];
                 s_ptr[k] = (u16)q;
-                open |= !(q & 0x8000);
+                if (q & 0x8000) open &= ~(1ull << j);
             }
+            if (!__syncthreads_or(open != 0)) break;
         }
-        if (!__syncthreads_or(open)) break;
     }
     if (stop_after == 3) return;
     for (int k = tid; k < X_T * X_T; k += 256) {
