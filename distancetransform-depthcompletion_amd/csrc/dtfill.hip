@@ -850,24 +850,36 @@ __global__ __launch_bounds__(256) void k_l2row(const float *__restrict__ x, cons
 // of a step are contiguous.  D(i) = min(E(i), 3 + D(i-1)) is scanned per chunk from "infinity"
 // (pass A), the true value at each chunk start follows from the chunk ends (LDS), and pass B rescans
 // from it and stores dB = 3 + D(previous row).
-__device__ __forceinline__ int skew_step(const u16 *__restrict__ guf, u16 *__restrict__ dBf, int W, int nU,
-                                         int u, int i, int D) {
-    const int j = u - 2 * i;
-    const bool on = (u < nU) && j >= 0 && j <= W;
-    const int dbv = min(D + 3, BIG);  // 3 + D(i-1, j+2)
-    int e = BIG;
-    if (on) {
-        const u16 *row = guf + (size_t)i * W;
-        if (j < W) {
-            if (dBf) dBf[(size_t)i * W + j] = st16(dbv);
-            e = ld16(row + j);
+// rows [c0, c1) of the lane's knight line.  8 rows at a time: their 16 loads are unconditional (clamped
+// addresses, the predicates are applied afterwards with selects), so they are all in flight together.
+// Returns D after row c1-1; if dBf, stores dB = 3 + D(previous row).
+__device__ __forceinline__ int skew_run(const u16 *__restrict__ guf, u16 *__restrict__ dBf, int W, int nU, int u,
+                                        int c0, int c1, int D) {
+    const bool lane_on = u < nU;
+    for (int ib = c0; ib < c1; ib += 8) {
+        int ga[8], gb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int i = min(ib + t, c1 - 1);
+            const int j = u - 2 * i;
+            const u16 *row = guf + (size_t)i * W;
+            ga[t] = row[min(max(j, 0), W - 1)];
+            gb[t] = row[min(max(j - 1, 0), W - 1)];
         }
-        if (j >= 1) {
-            const int t = ld16(row + j - 1);
-            if (t < BIG) e = min(e, t - 1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int i = ib + t;
+            const int j = u - 2 * i;
+            const bool on = lane_on && i < c1 && j >= 0 && j <= W;
+            const int dbv = min(D + 3, BIG);  // 3 + D(i-1, j+2)
+            const int a = ga[t] == INF16 ? BIG : ga[t], bq = gb[t] == INF16 ? BIG : gb[t] - 1;
+            int e = (on && j < W) ? a : BIG;
+            e = (on && j >= 1) ? min(e, bq) : e;
+            if (dBf && on && j < W) dBf[(size_t)i * W + j] = st16(dbv);
+            D = i < c1 ? (on ? min(e, dbv) : BIG) : D;
         }
     }
-    return on ? min(e, dbv) : BIG;
+    return D;
 }
 
 __global__ __launch_bounds__(64 * G_NCH) void k_skew(const u16 *__restrict__ gu, const int *__restrict__ fflag,
@@ -887,8 +899,7 @@ __global__ __launch_bounds__(64 * G_NCH) void k_skew(const u16 *__restrict__ gu,
     const int i_hi = min(H - 1, u1 / 2);
     const int CR = (i_hi - i_lo + 1 + G_NCH - 1) / G_NCH;
     const int c0 = min(i_lo + ch * CR, i_hi + 1), c1 = min(c0 + CR, i_hi + 1);
-    int D = BIG;
-    for (int i = c0; i < c1; ++i) D = skew_step(guf, nullptr, W, nU, u, i, D);
+    int D = skew_run(guf, nullptr, W, nU, u, c0, c1, BIG);
     s_end[ch][lane] = D;
     __syncthreads();
     // D just before row c0: chain the chunk ends (a line is "on" for one contiguous row range, and an
@@ -901,8 +912,7 @@ __global__ __launch_bounds__(64 * G_NCH) void k_skew(const u16 *__restrict__ gu,
         // before: K + 3 len stays >= BIG only if K was BIG -- which holds, because any earlier on-rows
         // would make the line on at the end of chunk c as well (it leaves the image only at its last row)
     }
-    D = K;
-    for (int i = c0; i < c1; ++i) D = skew_step(guf, dBf, W, nU, u, i, D);
+    skew_run(guf, dBf, W, nU, u, c0, c1, K);
 }
 
 // k_rowscan: one wave per image row, 8 consecutive pixels per lane (one 16-byte load per array), 512
