@@ -49,7 +49,7 @@ def DT_complete_batch(lidar_batch, src_thr=0.1, val_thr=0.1):
         raise IndexError("too many indices for array: DT_complete_batch indexes lidar_batch[i,:,:,0]")
     x = lb[:, :, :, 0]
     out = _device.default_op().run_numpy(x, src_thr=src_thr, val_thr=val_thr, want=("depth",))
-    return np.expand_dims(out["depth"], axis=-1).astype(np.float32)
+    return np.expand_dims(out["depth"], axis=-1)  # already a fresh float32 array
 
 
 def Distance_Transform(lidar, src_thr=0.001, val_thr=0.1):
