@@ -251,11 +251,19 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     // empty rows forces d >= ceil(k/2) in its middle row, d >= k at the border row if it touches the top or
     // bottom edge.  Each thread looks at the run ENDING at its rows (cheap: the counts are in L2).
     {
+        // "row has no source" as bits in LDS (H <= 8191 -> 256 words), so walking a run costs LDS reads only
+        __shared__ u32 s_empty[256];
+        s_empty[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < H; i += 256)
+            if (cs_[i] == 0) atomicOr(&s_empty[i >> 5], 1u << (i & 31));
+        __syncthreads();
+        auto empty = [&](int i) { return (s_empty[i >> 5] >> (i & 31)) & 1u; };
         int dlb = 0;
         for (int i = tid; i < H; i += 256) {
-            if (cs_[i] != 0 || (i + 1 < H && cs_[i + 1] == 0)) continue;  // not the last row of a run
+            if (!empty(i) || (i + 1 < H && empty(i + 1))) continue;  // not the last row of a run
             int k = 1;
-            while (i - k >= 0 && cs_[i - k] == 0) ++k;
+            while (i - k >= 0 && empty(i - k)) ++k;
             const bool edge = (i - k < 0) || (i + 1 >= H);
             dlb = max(dlb, (i - k < 0 && i + 1 >= H) ? BIG : edge ? k : (k + 1) / 2);
         }
@@ -1039,12 +1047,13 @@ constexpr int G_PPT = 16;  // pixels per thread in k_final (keeps its no-op grid
 //   otherwise  : pixel index (another tile) where the chain continues
 // Also stores the float distance map (the last consumer of d).
 constexpr int X_T = 128;             // tile edge
+constexpr int X_NT = 1024;           // threads per block
 constexpr int X_P = X_T + 4;         // dl tile pitch (2-cell halo each side)
 constexpr u32 X_ROOT = 0x80000000u;  // exit pointer: resolved to a root
 constexpr u32 X_NONE = 0x7FFFFFFFu;  // exit pointer: frame without sources
 constexpr int X_BORDER = 0x3FF0;     // dl value outside the image: (v & mask) + w never equals a d | live<<15
 
-__global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const int *__restrict__ fflag, int H,
+__global__ __launch_bounds__(X_NT) void k_exit(const u16 *__restrict__ dl, const int *__restrict__ fflag, int H,
                                               int W, int tiles_x, u32 *__restrict__ exitp,
                                               float *__restrict__ out_dt, int stop_after) {
     __shared__ __attribute__((aligned(16))) u16 s_big[X_P * X_P];  // dl tile + halo; later the pointers (X_T*X_T)
@@ -1060,11 +1069,11 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
     {   // tile + halo: one wave per row, lanes along the row (coalesced, no divisions); the loads of 8 rows
         // (24 per lane) are issued before the first LDS store, so the memory round trips overlap
         const int lane = tid & 63, wave = tid >> 6;
-        for (int rb = wave; rb < X_P; rb += 4 * 8) {
+        for (int rb = wave; rb < X_P; rb += (X_NT / 64) * 8) {
             u16 v[8][3];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int r = rb + 4 * u;
+                const int r = rb + (X_NT / 64) * u;
                 const int gi = r0 + r - 2;
                 const bool rin = r < X_P && gi >= 0 && gi < H;
                 const u16 *src = dlf + (size_t)(rin ? gi : 0) * W;
@@ -1076,7 +1085,7 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int r = rb + 4 * u;
+                const int r = rb + (X_NT / 64) * u;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int c = lane + 64 * q;
@@ -1089,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
     if (stop_after == 0) return;  // timing-only (DTFILL_EXIT_STOP)
     // parent rule, straight-line: tap t forward for live cells, the negated tap for the others; keep the
     // code format of tap_decode (t | backward << 3)
-    for (int k = tid; k < X_T * X_T; k += 256) {
+    for (int k = tid; k < X_T * X_T; k += X_NT) {
         const int r = k >> 7, c = k & (X_T - 1);
         const u16 *p = s_big + (r + 2) * X_P + c + 2;
         const int v = *p;
@@ -1114,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
     __syncthreads();
     if (stop_after == 1) return;
     u16 *s_ptr = s_big;  // the dl tile is dead
-    for (int k = tid; k < X_T * X_T; k += 256) {
+    for (int k = tid; k < X_T * X_T; k += X_NT) {
         const int r = k >> 7, c = k & (X_T - 1);
         const int code = s_code[k];
         int di, dj;
@@ -1131,13 +1140,13 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
     {
         u64 open = 0;
 #pragma unroll 8
-        for (int j = 0; j < X_T * X_T / 256; ++j) open |= (u64)(!(s_ptr[tid + 256 * j] & 0x8000)) << j;
+        for (int j = 0; j < X_T * X_T / X_NT; ++j) open |= (u64)(!(s_ptr[tid + X_NT * j] & 0x8000)) << j;
         for (int round = 0; round < 16; ++round) {  // 4^16 > any in-tile chain
             u64 m = open;
             while (m) {
                 const int j = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const int k = tid + 256 * j;
+                const int k = tid + X_NT * j;
                 int q = s_ptr[s_ptr[k]];  // s_ptr[k] has no flag: k is open
                 if (!(q & 0x8000)) q = s_ptr[q];
                 s_ptr[k] = (u16)q;
@@ -1147,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_exit(const u16 *__restrict__ dl, const 
         }
     }
     if (stop_after == 3) return;
-    for (int k = tid; k < X_T * X_T; k += 256) {
+    for (int k = tid; k < X_T * X_T; k += X_NT) {
         const int r = k >> 7, c = k & (X_T - 1);
         const int gi = r0 + r, gj = c0 + c;
         if (gi >= H || gj >= W) continue;
@@ -1395,7 +1404,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         mark();
         {
             const int etx = (W + X_T - 1) / X_T, ety = (H + X_T - 1) / X_T;
-            k_exit<<<dim3(etx * ety, B), 256, 0, st>>>(c.dl, c.fflag2, H, W, etx, c.exitp, out_dt, exit_stop);
+            k_exit<<<dim3(etx * ety, B), X_NT, 0, st>>>(c.dl, c.fflag2, H, W, etx, c.exitp, out_dt, exit_stop);
         }
         mark();
         k_final<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(
