@@ -349,6 +349,45 @@ def test_outlier_removal_vs_oracle(pkg, oracle):
         assert (want != x).any() or H < 8
 
 
+def test_concurrent_streams_and_threads(pkg, oracle):
+    """include/dtfill.h: no global state, every call ordered on its stream only.  Four operators (own
+    workspaces) driven from four host threads on four streams at once, several rounds, different inputs."""
+    import threading
+
+    import torch
+
+    rng = np.random.default_rng(9)
+    xs = [np.where(rng.random((3, 200, 300)) < p, rng.uniform(1, 80, (3, 200, 300)), 0).astype(np.float32)
+          for p in (0.05, 0.01, 0.002, 0.2)]
+    want = [oracle.fill_batch(x) for x in xs]
+    ops = [pkg.device.DtFill(device="cuda:0") for _ in xs]
+    streams = [torch.cuda.Stream(device="cuda:0") for _ in xs]
+    errors = []
+
+    def work(k):
+        try:
+            xd = torch.from_numpy(xs[k]).to("cuda:0")
+            torch.cuda.synchronize()
+            for _ in range(10):
+                with torch.cuda.stream(streams[k]):
+                    res = ops[k].run(xd)
+                    got = {n: v.clone() for n, v in res.items()}
+                streams[k].synchronize()
+                depth, dt, lbl, st = want[k]
+                assert np.array_equal(got["index"].cpu().numpy(), lbl)
+                assert np.array_equal(got["dt"].cpu().numpy(), dt)
+                assert np.array_equal(got["depth"].cpu().numpy(), depth)
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(xs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_shape_errors(gpu_op, pkg):
     import torch
 
