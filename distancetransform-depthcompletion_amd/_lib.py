@@ -48,13 +48,9 @@ class DtfillError(RuntimeError):
 
 def build(force=False):
     """Compile csrc/dtfill.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
-    src = os.path.join(CSRC, "dtfill.hip")
-    hdr = os.path.join(_HERE, "..", "include", "dtfill.h")
-    stale = (
-        force
-        or not os.path.exists(SO_PATH)
-        or os.path.getmtime(SO_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
-    )
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "dtfill.h"))
+    stale = force or not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < max(os.path.getmtime(f) for f in srcs)
     if stale:
         subprocess.check_call(["make", "-s", "-C", CSRC, "libdtfill.so"])
     return SO_PATH

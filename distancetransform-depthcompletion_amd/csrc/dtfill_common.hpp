@@ -1,0 +1,39 @@
+// dtfill_common.hpp -- constants, tap tables and small device helpers shared by every kernel
+// Part of libdtfill.so; included by dtfill.hip inside its anonymous namespace (one translation unit).
+#pragma once
+
+constexpr int BIG = 1 << 20;       // in-register "infinite" distance
+constexpr int INF16 = 0xFFFF;      // stored "infinite" distance in the uint16 scan arrays
+constexpr int DL_DMASK = 0x3FFF;   // dl: low 14 bits = d
+constexpr int DL_NONE = 0x3FFF;    // dl: no source in the frame
+constexpr int DL_LIVE = 0x8000;    // dl: live flag
+constexpr int PAR_SRC = 0xFF;      // parent code: pixel is a source
+constexpr int PAR_NONE = 0xFE;     // parent code: unreachable / undecided
+constexpr int MAX_HW_SUM = 8192;   // cv2's Q16 INIT_DIST0 = INT_MAX>>2 caps distances at 8191
+
+// frame facts written by k_frame: int32[FI_STRIDE] per frame
+constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_DLB = 3, FI_STRIDE = 4;  // DLB: lower bound of max d
+
+// cv2 tap order (OpenCV 3.4 distanceTransformEx_5x5), forward taps 0..7; backward tap t is the
+// NEGATED forward tap t with the same weight.  Parent code = t | (backward ? 8 : 0).
+#define TAP_DI(t) ((t) < 2 ? -2 : (t) < 7 ? -1 : 0)
+#define TAP_DJ(t) ((t) == 0 ? -1 : (t) == 1 ? 1 : (t) == 2 ? -2 : (t) == 3 ? -1 : (t) == 4 ? 0 : (t) == 5 ? 1 : (t) == 6 ? 2 : -1)
+#define TAP_W(t) ((t) < 3 ? 3 : (t) == 3 ? 2 : (t) == 4 ? 1 : (t) == 5 ? 2 : (t) == 6 ? 3 : 1)
+constexpr u32 TAP_DI_NIB = 0x21111100u;  // nibble t = di(t) + 2
+constexpr u32 TAP_DJ_NIB = 0x14321031u;  // nibble t = dj(t) + 2
+
+__device__ __forceinline__ void tap_decode(int code, int &di, int &dj) {
+    const int sh = (code & 7) * 4;
+    di = (int)((TAP_DI_NIB >> sh) & 15u) - 2;
+    dj = (int)((TAP_DJ_NIB >> sh) & 15u) - 2;
+    if (code & 8) {
+        di = -di;
+        dj = -dj;
+    }
+}
+
+__device__ __forceinline__ int ld16(const u16 *p) {
+    int v = *p;
+    return v == INF16 ? BIG : v;
+}
+__device__ __forceinline__ u16 st16(int v) { return (u16)(v >= INF16 ? INF16 : v); }

@@ -1,0 +1,374 @@
+// dtfill_fused.hpp -- k_fused<FR>: the bit-sliced LDS-window kernel of the l1_cv pass
+// Part of libdtfill.so; included by dtfill.hip inside its anonymous namespace (one translation unit).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// k_fused: one workgroup (2 waves) per window = tile (<= 96 x 160) + halo FR, bit-sliced.
+//
+// Lane r owns window row r as six 32-bit words per bit plane (bit c%32 of word c/32 = window column c).
+// Level-synchronous form of the identity in the file header (checked in
+// tests/parallel_model.py): with E_t = {d == t} and L_t = live pixels of E_t (E_0 = L_0 = sources),
+//   E_t = dilate4(D_{t-1}) & ~D_{t-1} & in-image
+//   forward tap T = (di,dj,w) offers   shift(L_{t-w}, di, dj)   to the pixels of E_t; L_t = those offered any
+//   backward tap (negated offset)      shift(E_{t-w}, -di, -dj) to E_t \ L_t
+//   the FIRST tap in cv2 order wins (taken-mask chain); the winning step is recorded in six "code planes"
+//   holding the bits of enc = (di+2)<<3 | (dj+2)  (sources: enc 18 = step (0,0)).
+// A horizontal shift of a row is one v_alignbit per word; rows r-2..r+2 of the previous three levels
+// come from a 4-slot LDS ring (one barrier per level).  Levels stop at FR or when a level is empty.
+// Then every lane un-slices its row, 4 pixels per step, into the byte array s_par (0x80 | enc; 0x80
+// itself = undecided), which reuses the ring's memory, and the tile pixels walk to their sources in
+// lock-step; d is |drow| + |dcol| to the root.
+// LDS: 25.3 KB ring/s_par + 6 KB bit words and ranks.
+// ------------------------------------------------------------------------------------------------
+constexpr int F_WHM = 128;  // window rows
+constexpr int F_WWM = 192;  // window columns = 6 words
+constexpr int F_NT = 256;   // lane = (row, half): waves 0-1 own words 0..2 of rows 0..127, waves 2-3 words 3..5
+constexpr int F_P = 196;               // s_par row pitch: 49 dwords (odd) -> lane-per-row dword stores are conflict-free
+constexpr int F_NWD = 6;               // 32-bit words per window row
+constexpr int F_HW = 3;                // words per lane
+constexpr int F_RS = 7;                // ring row stride in words: 6 + one zero pad (odd: conflict-free; the pad is
+                                       // also the zero "word -1" of the next row and "word 6" of this one)
+constexpr int F_RROWS = F_WHM + 4;     // ring rows: 2 zero rows above and below the window
+constexpr int F_RPLANE = F_RROWS * F_RS;
+constexpr int F_RING = 1 + 4 * 2 * F_RPLANE;  // one leading zero word, then [slot][plane E/L][row][7]
+constexpr int F_EB = 8;                // tile pixels per lane walked in lock-step
+// byte code of a source: 0x80 | 18 = step (0,0)
+constexpr int F_NONE = 0xC0 | 18;      // byte code of an undecided pixel: also step (0,0), plus bit 6
+static_assert(F_WWM == 32 * F_NWD, "window width must be six words");
+static_assert(F_RING * 4 >= F_WHM * F_P, "s_par must fit in the ring's memory");
+
+#define ENC_F(t) (((TAP_DI(t) + 2) << 3) | (TAP_DJ(t) + 2))
+
+// a[0..4] = the lane's three words a[1..3] with their left / right neighbour words; word i (0..2) of the
+// row shifted so that result[c] = row[c + DJ]
+template <int DJ>
+__device__ __forceinline__ u32 hshift(const u32 (&a)[5], int i) {
+    if (DJ == 0) return a[i + 1];
+    if (DJ > 0) return __builtin_amdgcn_alignbit(a[i + 2], a[i + 1], DJ);
+    return __builtin_amdgcn_alignbit(a[i + 1], a[i], 32 + DJ);
+}
+
+// one tap of the first-match chain: cand = shift(src, DJ); winners get the bits of ENC in the code planes
+template <int DJ, int ENC>
+__device__ __forceinline__ void tap_step(const u32 (&src)[5], u32 (&taken)[F_HW], u32 (&C)[6][F_HW]) {
+#pragma unroll
+    for (int i = 0; i < F_HW; ++i) {
+        const u32 cand = hshift<DJ>(src, i);
+        const u32 sel = cand & ~taken[i];
+        taken[i] |= cand;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (ENC & (1 << j)) C[j][i] |= sel;
+    }
+}
+
+// the lane's three words of a ring row plus one neighbour word on each side (pads / other half)
+__device__ __forceinline__ void ring_load5(const u32 *__restrict__ ring, int slot, int plane, int row, int wb,
+                                           u32 (&a)[5]) {
+    const u32 *p = ring + 1 + (slot * 2 + plane) * F_RPLANE + row * F_RS + wb - 1;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) a[i] = p[i];
+}
+__device__ __forceinline__ void ring_store3(u32 *__restrict__ ring, int slot, int plane, int row, int wb,
+                                            const u32 (&w)[F_HW]) {
+    u32 *p = ring + 1 + (slot * 2 + plane) * F_RPLANE + row * F_RS + wb;
+#pragma unroll
+    for (int i = 0; i < F_HW; ++i) p[i] = w[i];
+}
+
+// FR = halo = largest distance the window can decide.  gate (nullable): only frames with gate[b] != 0
+// are processed (the second, FR = 32 stage only redoes the frames the FR = 16 stage flagged).
+template <int FR>
+__global__ __launch_bounds__(F_NT) void k_fused(
+    const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
+    const u32 *__restrict__ rowbase_s, const int *__restrict__ finfo, const float *__restrict__ vlist,
+    int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
+    float *__restrict__ out_dt, int32_t *__restrict__ out_index, const int *__restrict__ gate,
+    int *__restrict__ fflag, int *__restrict__ frame_status, int stop_after) {
+    if (gate && !gate[blockIdx.y]) return;
+    // Speed heuristic only (never correctness): with source density p the chance that a pixel has no source
+    // within L1 distance FR is about (1-p)^(2 FR^2 + 2 FR + 1); if the frame is expected to hold such a pixel
+    // anyway (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), this stage would only flag the frame after doing
+    // all the work -- hand it on right away.  Likewise when k_frame found a run of source-free rows that forces
+    // some distance above FR (real LiDAR frames: the empty sky rows).  (The two finfo loads are issued together
+    // with the window loads below; the branch comes after those are in flight.)
+    const long long h_nsrc = finfo[blockIdx.y * FI_STRIDE + FI_NSRC];
+    const int h_dlb = finfo[blockIdx.y * FI_STRIDE + FI_DLB];
+    __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
+    __shared__ u32 s_sb[F_WHM * 8];  // source bits of the window rows, image-aligned 64-pixel words (as u32 pairs)
+    __shared__ u32 s_rk[F_WHM * 4];  // sources before each of those 64-pixel words (frame raster order)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NWAVE = F_NT / 64;
+    const int b = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int r0 = ty * TH, c0 = tx * TW;
+    const int th = min(TH, H - r0), tw = min(TW, W - c0);
+    const int wr0 = r0 - FR, wc0 = c0 - FR;  // image coords of window cell (0,0)
+    const int WH = th + 2 * FR, WW = tw + 2 * FR;
+    const int ca = max(0, -wc0), cb = min(WW, W - wc0);  // in-image window columns [ca, cb)
+    const int ra = max(0, -wr0), rb = min(WH, H - wr0);  // in-image window rows
+    const int w0 = wc0 >> 6;                             // first image word column the window touches (-1 if wc0 < 0)
+    const int sh = wc0 - 64 * w0;                        // window column 0 is bit sh of image word w0
+
+    // ---- P0: this lane's half row: image-aligned words -> LDS (for the ranks), window-aligned planes -> registers
+    const int r = tid & (F_WHM - 1);  // window row of this lane
+    const int hf = tid >> 7;          // which half of the row (wave-uniform)
+    const int wb = F_HW * hf;         // first of the lane's three words
+    u32 M[F_HW], D[F_HW];
+    {
+        const int gi = wr0 + r;
+        const bool rowin = r < WH && gi >= 0 && gi < H;
+        // the lane's 96 window columns start at bit sh + 96 hf of the row's image-aligned bit string;
+        // three image words (192 bits) starting at word (sh + 96 hf) / 64 cover them
+        const int bit0 = sh + 96 * hf;
+        const int kw = bit0 >> 6;  // wave-uniform
+        u32 g[7];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int kk = kw + k;  // 0..3 relative to w0
+            const int w = w0 + kk;
+            u64 sb = 0;
+            u32 rk = 0;
+            if (rowin && kk < 4 && w >= 0 && w < Wd) {
+                const size_t wi = ((size_t)b * H + gi) * Wd + w;
+                sb = srcbits[wi];
+                rk = rowbase_s[(size_t)b * H + gi] + wpre_s[wi];
+            }
+            g[2 * k] = (u32)sb;
+            g[2 * k + 1] = (u32)(sb >> 32);
+            // each of the four image words of a row is stored once: half 0 stores its words kk = 0, 1 (and 2
+            // if half 1 starts later), half 1 the rest
+            const bool mine = hf == 0 ? kk < 2 : (kk >= 2 && kk < 4);
+            if (mine) {
+                s_sb[r * 8 + 2 * kk] = g[2 * k];
+                s_sb[r * 8 + 2 * kk + 1] = g[2 * k + 1];
+                s_rk[r * 4 + kk] = rk;
+            }
+        }
+        g[6] = 0;
+        const int s6 = bit0 & 63;
+        const bool hi = s6 & 32;  // wave-uniform
+        const int s5 = s6 & 31;
+#pragma unroll
+        for (int i = 0; i < F_HW; ++i) {
+            const u32 lo_w = hi ? g[i + 1] : g[i], hi_w = hi ? g[i + 2] : g[i + 1];
+            const u32 word = s5 ? __builtin_amdgcn_alignbit(hi_w, lo_w, s5) : lo_w;
+            // in-image columns of window word wb + i: [max(ca, 32 (wb+i)), min(cb, 32 (wb+i) + 32))
+            const int lo = max(ca - 32 * (wb + i), 0), up = min(cb - 32 * (wb + i), 32);
+            u32 m = 0;
+            if (rowin && up > lo) m = (up >= 32 ? 0xFFFFFFFFu : ((1u << up) - 1u)) & ~((1u << lo) - 1u);
+            M[i] = m;
+            D[i] = word & m;
+        }
+    }
+    if (h_nsrc * (2 * FR * FR + 2 * FR + 1) < 14ll * H * W || h_dlb > FR) {  // block-uniform
+        if (threadIdx.x == 0 && blockIdx.x == 0) {
+            fflag[blockIdx.y] = 1;
+            if (FR == 32) atomicOr(frame_status + blockIdx.y, DTFILL_FRAME_GENERAL_PATH);
+        }
+        return;
+    }
+    // level 0: E_0 = L_0 = sources; zero the rest of the ring (levels "-1,-2,-3", the guard rows, the pads)
+    for (int k = tid; k < F_RING; k += F_NT) s_ring[k] = 0;
+    __syncthreads();
+    ring_store3(s_ring, 0, 0, r + 2, wb, D);
+    ring_store3(s_ring, 0, 1, r + 2, wb, D);
+    u32 C[6][F_HW];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int i = 0; i < F_HW; ++i) C[j][i] = ((18 >> j) & 1) ? D[i] : 0u;  // sources: enc 18
+    u32 Dup[F_HW], Ddn[F_HW];
+    u32 Dl = 0, Dr = 0;  // D's neighbour words left / right of the lane's three (other half or nothing)
+#pragma unroll
+    for (int i = 0; i < F_HW; ++i) Dup[i] = Ddn[i] = 0;
+    __syncthreads();
+    if (stop_after == 0) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
+
+    // ---- P1: levels
+    for (int t = 1; t <= FR; ++t) {
+        const int s1 = (t - 1) & 3, s2 = (t - 2) & 3, s3 = (t - 3) & 3, sw = t & 3;
+        u32 nb[5], e1[5], l1[5], taken[F_HW], Et[F_HW], Lt[F_HW];
+        // dilation of D_{t-1}: left/right in registers (+ the neighbour words), up/down through E_{t-1}
+        ring_load5(s_ring, s1, 0, r + 2, wb, e1);  // E_{t-1}, this row (also the last tap's source)
+        Dl |= e1[0];
+        Dr |= e1[4];
+        ring_load5(s_ring, s1, 0, r + 1, wb, nb);  // E_{t-1}, row r-1
+#pragma unroll
+        for (int i = 0; i < F_HW; ++i) Dup[i] |= nb[i + 1];
+        u32 e1d[5];
+        ring_load5(s_ring, s1, 0, r + 3, wb, e1d);  // E_{t-1}, row r+1
+        bool nonempty = false;
+        {
+            const u32 dd[5] = {Dl, D[0], D[1], D[2], Dr};
+#pragma unroll
+            for (int i = 0; i < F_HW; ++i) {
+                Ddn[i] |= e1d[i + 1];
+                const u32 dil = hshift<1>(dd, i) | hshift<-1>(dd, i) | Dup[i] | Ddn[i];
+                Et[i] = dil & ~D[i] & M[i];
+                taken[i] = ~Et[i];
+                nonempty |= Et[i] != 0;
+            }
+        }
+        // forward taps in cv2 order; the candidates are live pixels of levels t-3, t-2, t-1
+        ring_load5(s_ring, s3, 1, r + 0, wb, nb);  // L_{t-3}, row r-2
+        tap_step<-1, ENC_F(0)>(nb, taken, C);
+        tap_step<1, ENC_F(1)>(nb, taken, C);
+        {
+            u32 l3[5], l2[5];
+            ring_load5(s_ring, s3, 1, r + 1, wb, l3);  // L_{t-3}, row r-1
+            ring_load5(s_ring, s2, 1, r + 1, wb, l2);  // L_{t-2}, row r-1
+            ring_load5(s_ring, s1, 1, r + 1, wb, nb);  // L_{t-1}, row r-1
+            tap_step<-2, ENC_F(2)>(l3, taken, C);
+            tap_step<-1, ENC_F(3)>(l2, taken, C);
+            tap_step<0, ENC_F(4)>(nb, taken, C);
+            tap_step<1, ENC_F(5)>(l2, taken, C);
+            tap_step<2, ENC_F(6)>(l3, taken, C);
+        }
+        ring_load5(s_ring, s1, 1, r + 2, wb, l1);  // L_{t-1}, this row
+        tap_step<-1, ENC_F(7)>(l1, taken, C);
+#pragma unroll
+        for (int i = 0; i < F_HW; ++i) {
+            Lt[i] = taken[i] & Et[i];
+            taken[i] = ~(Et[i] & ~Lt[i]);  // backward chain only for the non-live pixels of E_t
+        }
+        // backward taps (negated offsets, same order); candidates are ALL pixels of levels t-3, t-2, t-1
+        ring_load5(s_ring, s3, 0, r + 4, wb, nb);  // E_{t-3}, row r+2
+        tap_step<1, 36 - ENC_F(0)>(nb, taken, C);
+        tap_step<-1, 36 - ENC_F(1)>(nb, taken, C);
+        {
+            u32 e3[5], e2[5];
+            ring_load5(s_ring, s3, 0, r + 3, wb, e3);  // E_{t-3}, row r+1
+            ring_load5(s_ring, s2, 0, r + 3, wb, e2);  // E_{t-2}, row r+1
+            tap_step<2, 36 - ENC_F(2)>(e3, taken, C);
+            tap_step<1, 36 - ENC_F(3)>(e2, taken, C);
+            tap_step<0, 36 - ENC_F(4)>(e1d, taken, C);
+            tap_step<-1, 36 - ENC_F(5)>(e2, taken, C);
+            tap_step<-2, 36 - ENC_F(6)>(e3, taken, C);
+        }
+        tap_step<1, 36 - ENC_F(7)>(e1, taken, C);
+#pragma unroll
+        for (int i = 0; i < F_HW; ++i) D[i] |= Et[i];
+        ring_store3(s_ring, sw, 0, r + 2, wb, Et);
+        ring_store3(s_ring, sw, 1, r + 2, wb, Lt);
+        if (!__syncthreads_or(nonempty)) break;  // nothing at distance t anywhere: nothing farther either
+    }
+    if (stop_after == 1) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
+
+    // ---- P2: un-slice the code planes of this half row into bytes, 4 pixels per step.
+    // ((nibble * 0x00204081) & 0x01010101) spreads bits 0..3 of the nibble to the low bits of 4 bytes.
+    u8 *s_par = reinterpret_cast<u8 *>(s_ring);
+    __syncthreads();  // the ring is dead for everybody before its memory becomes s_par
+    {
+        u32 *prow = reinterpret_cast<u32 *>(s_par + r * F_P) + wb * 8;
+#pragma unroll
+        for (int i = 0; i < F_HW; ++i) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                u32 v = 0x80808080u;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const u32 nib = (C[j][i] >> (4 * q)) & 0xFu;
+                    v |= ((nib * 0x00204081u) & 0x01010101u) << j;
+                }
+                // undecided pixels (not in D): no plane bit is set; give them F_NONE = 0x80 | 0x52
+                const u32 und = ((~D[i] >> (4 * q)) & 0xFu) * 0x00204081u & 0x01010101u;
+                prow[i * 8 + q] = v | und * 0x52u;
+            }
+        }
+    }
+    __syncthreads();
+    if (stop_after == 2) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
+
+    // ---- P3: tile pixels: walk to the source, d, rank -> label, gather, store.  Each lane walks F_EB
+    // pixels in lock-step (their LDS reads are independent, so the hop latencies overlap) and then has
+    // F_EB global gathers in flight together.
+    const size_t fo = (size_t)b * H * W;
+    const int nval = finfo[b * FI_STRIDE + FI_NVAL];
+    const int misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
+    bool overflow = false;
+    for (int tc = lane; tc < tw; tc += 64) {
+        const int cc = FR + tc;
+        for (int trb = wave; trb < th; trb += NWAVE * F_EB) {
+            int pos[F_EB], code[F_EB];  // pos = row * F_P + col: byte index of the walker in s_par
+            bool ok[F_EB];
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) {
+                const int tr = trb + e * NWAVE;
+                pos[e] = (FR + min(tr, th - 1)) * F_P + cc;
+                code[e] = s_par[pos[e]];
+                ok[e] = tr < th && code[e] != F_NONE;
+                overflow |= tr < th && code[e] == F_NONE;  // undecidable here: the frame takes the general path
+            }
+            // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
+            // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
+            // overlap.  Two hops between "everybody arrived?" checks.
+            for (int hop = 0; hop < FR; hop += 2) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                    for (int e = 0; e < F_EB; ++e) {
+                        const int c = code[e];
+                        pos[e] += (int)((c >> 3) & 7) * F_P + (c & 7) - (2 * F_P + 2);
+                    }
+#pragma unroll
+                    for (int e = 0; e < F_EB; ++e) code[e] = s_par[pos[e]];
+                }
+                int notdone = 0;
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) notdone |= (code[e] | 0x40) ^ F_NONE;  // 0 iff step (0,0)
+                if (!__any(notdone != 0)) break;
+            }
+            if (stop_after == 3) {  // timing only: keep the walk alive, skip the rest
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(pos[e]));
+                continue;
+            }
+            int lab[F_EB], goff[F_EB], dd[F_EB];
+            float val[F_EB];
+            bool bad = false;
+            const float *gbase = misaligned ? vlist + fo : x + fo;  // block-uniform
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) {
+                // a decided chain ends on a source inside the in-image window; the clamps only make sure
+                // that a logic error could never become a wild global access
+                const int pr_ = pos[e] / F_P, pc_ = pos[e] - pr_ * F_P;
+                const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
+                const int tr = min(trb + e * NWAVE, th - 1);
+                dd[e] = abs(r_ - (FR + tr)) + abs(c_ - cc);  // L1 distance to the nearest source IS d
+                const int gj = wc0 + c_;
+                const int k = r_ * 4 + (gj >> 6) - w0;
+                const u32 lo = s_sb[2 * k], hi = s_sb[2 * k + 1];
+                const u32 below = (1u << (gj & 31)) - 1u;
+                lab[e] = (int)s_rk[k] + ((gj & 32) ? __popc(lo) + __popc(hi & below) : __popc(lo & below)) + 1;
+                // depth_list[label-1] (tools.py:26).  A decided pixel has label >= 1, so the numpy wrap of
+                // index -1 cannot occur here; an index past the value list is numpy's IndexError.
+                const int idx = lab[e] - 1;
+                const bool oob = idx >= nval;
+                bad |= ok[e] && oob;
+                goff[e] = oob ? 0 : (misaligned ? idx : (wr0 + r_) * W + gj);  // masks agree: the label-th value is x at the source
+            }
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) val[e] = gbase[goff[e]];
+            if (stop_after == 4) {
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(val[e]), "v"(lab[e]), "v"(dd[e]));
+                continue;
+            }
+            if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) {
+                if (!ok[e]) continue;
+                const size_t o = fo + (size_t)(r0 + trb + e * NWAVE) * W + (c0 + tc);
+                if (out_index) out_index[o] = lab[e];
+                if (out_dt) out_dt[o] = (float)dd[e];
+                if (out_depth) out_depth[o] = val[e];
+            }
+        }
+    }
+    if (overflow) {
+        fflag[b] = 1;  // same-value race
+        if (FR == 32) atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);  // last fused stage: general path next
+    }
+}

@@ -1,0 +1,485 @@
+// dtfill_general.hpp -- k_colscan, k_skew, k_rowscan, k_exit, k_final: full-frame scans, any distance
+// Part of libdtfill.so; included by dtfill.hip inside its anonymous namespace (one translation unit).
+#pragma once
+
+// ================================================================================================
+// General path (any distance).  Every kernel returns at once for frames k_fused did not flag.
+// ================================================================================================
+
+constexpr int G_NCH = 16;  // row chunks (= waves per block) of the chunked column / knight-line scans
+
+// k_colscan: 64 adjacent image columns per block, one wave per chunk of rows.
+//   pass A: last / first source row of every column inside the chunk -> LDS
+//   pass B: carry in the nearest source row above / below the chunk, then
+//           down sweep: gu(i,j) = rows to the nearest source at or above (i,j);  up sweep: g = min(gu, gd).
+// L2 = true (the `l2` metric): g carries in bit 15 whether that nearest source is BELOW the pixel (strictly
+// nearer than the one above: on a vertical tie the upper source has the smaller raster index).
+template <bool L2>
+__global__ __launch_bounds__(64 * G_NCH) void k_colscan(const u64 *__restrict__ srcbits,
+                                                        const int *__restrict__ fflag, int H, int W, int Wd,
+                                                        int CR, u16 *__restrict__ gu, u16 *__restrict__ g) {
+    __shared__ int s_last[G_NCH][64], s_first[G_NCH][64];
+    const int b = blockIdx.y, wd = blockIdx.x, lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    if (fflag && !fflag[b]) return;
+    const int j = wd * 64 + lane;
+    const bool inb = j < W;
+    const size_t fo = (size_t)b * H * W;
+    u16 *guf = gu + fo, *gf = g + fo;
+    const u64 *sbf = srcbits + (size_t)b * H * Wd + wd;
+    const int i0 = min(ch * CR, H), i1 = min(i0 + CR, H);
+
+    int last = -BIG, first = BIG;
+    for (int i = i0; i < i1; ++i) {
+        const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
+        last = s ? i : last;
+        first = s ? min(first, i) : first;
+    }
+    s_last[ch][lane] = last;
+    s_first[ch][lane] = first;
+    __syncthreads();
+    int above = -BIG, below = BIG;
+#pragma unroll
+    for (int c = 0; c < G_NCH; ++c) {
+        above = c < ch ? max(above, s_last[c][lane]) : above;
+        below = c > ch ? min(below, s_first[c][lane]) : below;
+    }
+    int up = min(i0 - 1 - above, BIG);  // value "at row i0-1"
+    int dn = min(below - i1, BIG);      // value "at row i1"
+    if (CR <= 32) {
+        // fast path (H <= 512): the chunk's source bits sit in one register, the from-below distances of its
+        // rows in (statically indexed) registers; one store pass, nothing is re-read
+        u32 bits = 0;
+        for (int i = i0; i < i1; ++i) bits |= (u32)((sbf[(size_t)i * Wd] >> lane) & 1ull) << (i - i0);
+        const int n = i1 - i0;
+        int dnv[32];
+#pragma unroll
+        for (int k = 31; k >= 0; --k) {
+            if (k < n) dn = (bits >> k) & 1u ? 0 : min(dn + 1, BIG);  // rows past the chunk end leave dn at "row i1"
+            dnv[k] = dn;
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (k < n) {
+                up = (bits >> k) & 1u ? 0 : min(up + 1, BIG);
+                if (inb) {
+                    const size_t o = (size_t)(i0 + k) * W + j;
+                    guf[o] = st16(up);
+                    if (L2) {
+                        const int m = min(up, dnv[k]);
+                        gf[o] = m >= 0x7FFF ? (u16)INF16 : (u16)(m | (dnv[k] < up ? 0x8000 : 0));
+                    } else {
+                        gf[o] = st16(min(up, dnv[k]));
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) {
+        const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
+        up = s ? 0 : min(up + 1, BIG);
+        if (inb) guf[(size_t)i * W + j] = st16(up);
+    }
+#pragma unroll 4
+    for (int i = i1 - 1; i >= i0; --i) {
+        const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
+        dn = s ? 0 : min(dn + 1, BIG);
+        if (inb) {
+            const int u = ld16(guf + (size_t)i * W + j);
+            if (L2) {
+                const int m = min(u, dn);
+                gf[(size_t)i * W + j] = m >= 0x7FFF ? (u16)INF16 : (u16)(m | (dn < u ? 0x8000 : 0));
+            } else {
+                gf[(size_t)i * W + j] = st16(min(u, dn));
+            }
+        }
+    }
+}
+
+
+// k_skew: knight lines u = j + 2 i over the extended column range j in [0, W] (column W is virtual:
+// E(i,W) = gu(i,W-1) - 1).  64 adjacent lines per block, one wave per chunk of the rows those lines
+// cross; all lanes of a wave sit in the same image row at each step, so the gu reads and dB writes
+// of a step are contiguous.  D(i) = min(E(i), 3 + D(i-1)) is scanned per chunk from "infinity"
+// (pass A), the true value at each chunk start follows from the chunk ends (LDS), and pass B rescans
+// from it and stores dB = 3 + D(previous row).
+// rows [c0, c1) of the lane's knight line.  8 rows at a time: their 16 loads are unconditional (clamped
+// addresses, the predicates are applied afterwards with selects), so they are all in flight together.
+// Returns D after row c1-1; if dBf, stores dB = 3 + D(previous row).
+__device__ __forceinline__ int skew_run(const u16 *__restrict__ guf, u16 *__restrict__ dBf, int W, int nU, int u,
+                                        int c0, int c1, int D) {
+    const bool lane_on = u < nU;
+    for (int ib = c0; ib < c1; ib += 8) {
+        int ga[8], gb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int i = min(ib + t, c1 - 1);
+            const int j = u - 2 * i;
+            const u16 *row = guf + (size_t)i * W;
+            ga[t] = row[min(max(j, 0), W - 1)];
+            gb[t] = row[min(max(j - 1, 0), W - 1)];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int i = ib + t;
+            const int j = u - 2 * i;
+            const bool on = lane_on && i < c1 && j >= 0 && j <= W;
+            const int dbv = min(D + 3, BIG);  // 3 + D(i-1, j+2)
+            const int a = ga[t] == INF16 ? BIG : ga[t], bq = gb[t] == INF16 ? BIG : gb[t] - 1;
+            int e = (on && j < W) ? a : BIG;
+            e = (on && j >= 1) ? min(e, bq) : e;
+            if (dBf && on && j < W) dBf[(size_t)i * W + j] = st16(dbv);
+            D = i < c1 ? (on ? min(e, dbv) : BIG) : D;
+        }
+    }
+    return D;
+}
+
+__global__ __launch_bounds__(64 * G_NCH) void k_skew(const u16 *__restrict__ gu, const int *__restrict__ fflag,
+                                                     int H, int W, u16 *__restrict__ dB) {
+    __shared__ int s_end[G_NCH][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    if (!fflag[b]) return;
+    const int nU = W + 2 * (H - 1) + 1;
+    const int u0 = blockIdx.x * 64;
+    const int u = u0 + lane;
+    const int u1 = min(u0 + 63, nU - 1);
+    const size_t fo = (size_t)b * H * W;
+    const u16 *guf = gu + fo;
+    u16 *dBf = dB + fo;
+
+    const int i_lo = max(0, (u0 - W + 1) / 2);  // first row any lane of this block is inside [0, W]
+    const int i_hi = min(H - 1, u1 / 2);
+    const int CR = (i_hi - i_lo + 1 + G_NCH - 1) / G_NCH;
+    const int c0 = min(i_lo + ch * CR, i_hi + 1), c1 = min(c0 + CR, i_hi + 1);
+    int D = skew_run(guf, nullptr, W, nU, u, c0, c1, BIG);
+    s_end[ch][lane] = D;
+    __syncthreads();
+    // D just before row c0: chain the chunk ends (a line is "on" for one contiguous row range, and an
+    // "off" row resets D to BIG exactly as in the local scans)
+    int K = BIG;
+    for (int c = 0; c < ch; ++c) {
+        const int len = min(i_lo + (c + 1) * CR, i_hi + 1) - min(i_lo + c * CR, i_hi + 1);
+        K = min(s_end[c][lane], min(K + 3 * len, BIG));
+        // a line that was off at the end of chunk c has s_end == BIG and, being contiguous, was never on
+        // before: K + 3 len stays >= BIG only if K was BIG -- which holds, because any earlier on-rows
+        // would make the line on at the end of chunk c as well (it leaves the image only at its last row)
+    }
+    skew_run(guf, dBf, W, nU, u, c0, c1, K);
+}
+
+// k_rowscan: one wave per image row, 8 consecutive pixels per lane (one 16-byte load per array), 512
+// pixels per segment.  With a(j) = min_{k<=j} g(k) + (j-k) and dA likewise from gu (left-to-right), then
+// d(j) = min_{k>=j} a(k) + (k-j) over a itself (right-to-left; a <= g and a(k)+(k-j) is a real path length,
+// so this equals the two-sided minimum over g):  live = (dA == d) or (dB == d).
+// Inside a lane the scans are sequential (8 steps); across lanes ONE wave scan of the lane totals per
+// segment and quantity; across segments a wave-uniform carry.  The left-to-right results wait in a
+// per-wave LDS row buffer.
+__device__ __forceinline__ int wave_excl_prefix_min(int v, int lane) {  // min over lanes < lane (BIG for lane 0)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, off);
+        if (lane >= off) v = min(v, t);
+    }
+    const int e = __shfl_up(v, 1);
+    return lane == 0 ? BIG : e;
+}
+__device__ __forceinline__ int wave_excl_suffix_min(int v, int lane) {  // min over lanes > lane (BIG for lane 63)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_down(v, off);
+        if (lane + off < 64) v = min(v, t);
+    }
+    const int e = __shfl_down(v, 1);
+    return lane == 63 ? BIG : e;
+}
+
+// 8 consecutive uint16 of a row starting at element idx0 (multiple of 8); vectorised when the row is 16-byte aligned
+__device__ __forceinline__ void load8(const u16 *__restrict__ row, int idx0, int W, bool vec, int (&v)[8]) {
+    if (vec && idx0 + 8 <= W) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(row + idx0);
+        v[0] = q.x & 0xFFFF; v[1] = q.x >> 16; v[2] = q.y & 0xFFFF; v[3] = q.y >> 16;
+        v[4] = q.z & 0xFFFF; v[5] = q.z >> 16; v[6] = q.w & 0xFFFF; v[7] = q.w >> 16;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = idx0 + q < W ? (int)row[idx0 + q] : INF16;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = v[q] == INF16 ? BIG : v[q];
+}
+
+__global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, const u16 *__restrict__ gu,
+                                                 const u16 *__restrict__ dB, const int *__restrict__ fflag,
+                                                 int H, int W, int nseg, u16 *__restrict__ dl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * (blockDim.x >> 6) + wave, b = blockIdx.y;
+    if (!fflag[b] || i >= H) return;  // wave-uniform; no block-level barrier below
+    int *s_a = reinterpret_cast<int *>(smem) + (size_t)wave * nseg * 512;  // a | (dA == a) << 24, lane-private slots
+    const size_t ro = ((size_t)b * H + i) * W;
+    const u16 *grow = g + ro, *gurow = gu + ro, *dBrow = dB + ro;
+    const bool vec = (W & 7) == 0;  // rows start 16-byte aligned (the arrays are 256-byte aligned)
+
+    int carry_a = BIG, carry_dA = BIG;  // min of (value - index) over everything left of the segment
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int idx0 = sg * 512 + lane * 8;
+        int gv[8], uv[8];
+        load8(grow, idx0, W, vec, gv);
+        load8(gurow, idx0, W, vec, uv);
+        int ma = BIG, md = BIG, la[8], ld[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            ma = min(ma, gv[q] - (idx0 + q));
+            md = min(md, uv[q] - (idx0 + q));
+            la[q] = ma;
+            ld[q] = md;
+        }
+        const int ea = min(wave_excl_prefix_min(ma, lane), carry_a);
+        const int ed = min(wave_excl_prefix_min(md, lane), carry_dA);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int a = min(min(la[q], ea) + idx0 + q, BIG);
+            const int dA = min(min(ld[q], ed) + idx0 + q, BIG);
+            s_a[sg * 512 + q * 64 + lane] = a | (dA == a ? 1 << 24 : 0);  // [q][lane]: conflict-free, lane-private
+        }
+        carry_a = __shfl(min(ma, ea), 63);
+        carry_dA = __shfl(min(md, ed), 63);
+    }
+    int carry_b = BIG;  // min of (a + index) over everything right of the segment
+    for (int sg = nseg - 1; sg >= 0; --sg) {
+        const int idx0 = sg * 512 + lane * 8;
+        int av[8], fl[8], ms = BIG, ls[8];
+#pragma unroll
+        for (int q = 7; q >= 0; --q) {
+            const int v = s_a[sg * 512 + q * 64 + lane];
+            av[q] = v & 0xFFFFFF;
+            fl[q] = v >> 24;
+            ms = min(ms, av[q] + idx0 + q);
+            ls[q] = ms;
+        }
+        const int es = min(wave_excl_suffix_min(ms, lane), carry_b);
+        int dbv[8];
+        load8(dBrow, idx0, W, vec, dbv);
+        u32 out[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int d = min(ls[q], es) - (idx0 + q);
+            const bool live = (fl[q] && av[q] == d) || dbv[q] == d;
+            out[q] = d >= DL_NONE ? (u32)DL_NONE : (u32)(d | (live ? DL_LIVE : 0));  // DL_NONE: no source in the frame
+        }
+        carry_b = __shfl(min(ms, es), 0);
+        if (vec && idx0 + 8 <= W) {
+            uint4 o;
+            o.x = out[0] | out[1] << 16; o.y = out[2] | out[3] << 16; o.z = out[4] | out[5] << 16; o.w = out[6] | out[7] << 16;
+            *reinterpret_cast<uint4 *>(dl + ro + idx0) = o;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (idx0 + q < W) dl[ro + idx0 + q] = (u16)out[q];
+        }
+    }
+}
+
+constexpr int G_PPT = 16;  // pixels per thread in k_final (keeps its no-op grid small)
+
+// k_exit: one block per 128 x 128 tile.  Loads the tile of dl (d | live<<15) with a 2-cell halo into LDS,
+// applies the 5x5 parent rule there, and resolves the chains inside the tile by pointer doubling in LDS
+// (every cell does the same work each round: no divergent walks, and the number of rounds is log2 of the
+// longest in-tile chain, whatever the distances are).  A cell is terminal if it is a source, has no
+// parent, or its parent lies outside the tile.  Result per pixel: an exit pointer
+//   bit 31 set : the chain's root source, pixel index in the low bits
+//   0x7FFFFFFF : no source in the frame
+//   otherwise  : pixel index (another tile) where the chain continues
+// Also stores the float distance map (the last consumer of d).
+constexpr int X_T = 128;             // tile edge
+constexpr int X_NT = 1024;           // threads per block
+constexpr int X_P = X_T + 4;         // dl tile pitch (2-cell halo each side)
+constexpr u32 X_ROOT = 0x80000000u;  // exit pointer: resolved to a root
+constexpr u32 X_NONE = 0x7FFFFFFFu;  // exit pointer: frame without sources
+constexpr int X_BORDER = 0x3FF0;     // dl value outside the image: (v & mask) + w never equals a d | live<<15
+
+__global__ __launch_bounds__(X_NT) void k_exit(const u16 *__restrict__ dl, const int *__restrict__ fflag, int H,
+                                              int W, int tiles_x, u32 *__restrict__ exitp,
+                                              float *__restrict__ out_dt, int stop_after) {
+    __shared__ __attribute__((aligned(16))) u16 s_big[X_P * X_P];  // dl tile + halo; later the pointers (X_T*X_T)
+    __shared__ u8 s_code[X_T * X_T];
+    const int b = blockIdx.y;
+    if (!fflag[b]) return;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int r0 = ty * X_T, c0 = tx * X_T;
+    const size_t fo = (size_t)b * H * W;
+    const u16 *dlf = dl + fo;
+    const int tid = threadIdx.x;
+
+    {   // tile + halo: one wave per row, lanes along the row (coalesced, no divisions); the loads of 8 rows
+        // (24 per lane) are issued before the first LDS store, so the memory round trips overlap
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int rb = wave; rb < X_P; rb += (X_NT / 64) * 8) {
+            u16 v[8][3];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + (X_NT / 64) * u;
+                const int gi = r0 + r - 2;
+                const bool rin = r < X_P && gi >= 0 && gi < H;
+                const u16 *src = dlf + (size_t)(rin ? gi : 0) * W;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int c = lane + 64 * q, gj = c0 + c - 2;
+                    v[u][q] = (rin && c < X_P && gj >= 0 && gj < W) ? src[gj] : (u16)X_BORDER;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + (X_NT / 64) * u;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int c = lane + 64 * q;
+                    if (r < X_P && c < X_P) s_big[r * X_P + c] = v[u][q];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (stop_after == 0) return;  // timing-only (DTFILL_EXIT_STOP)
+    // parent rule, straight-line: tap t forward for live cells, the negated tap for the others; keep the
+    // code format of tap_decode (t | backward << 3)
+    for (int k = tid; k < X_T * X_T; k += X_NT) {
+        const int r = k >> 7, c = k & (X_T - 1);
+        const u16 *p = s_big + (r + 2) * X_P + c + 2;
+        const int v = *p;
+        const int d = v & DL_DMASK;
+        const int live = v >> 15;
+        const int sgn = live ? 1 : -1;
+        const int msk = live ? 0xFFFF : DL_DMASK;
+        int t_sel = -1;
+#pragma unroll
+        for (int t = 7; t >= 0; --t) {  // descending: the FIRST matching tap is kept
+            const int nv = p[sgn * (TAP_DI(t) * X_P + TAP_DJ(t))];
+            t_sel = ((nv & msk) + TAP_W(t) == v) ? t : t_sel;
+        }
+        int code = t_sel < 0 ? PAR_NONE : (t_sel | (live ? 0 : 8));
+        code = d == DL_NONE ? PAR_NONE : code;
+        code = d == 0 ? PAR_SRC : code;
+        s_code[k] = (u8)code;
+        const int gi = r0 + r, gj = c0 + c;
+        if (out_dt && gi < H && gj < W)
+            out_dt[fo + (size_t)gi * W + gj] = d == DL_NONE ? 8192.0f : (float)d;  // float(INIT_DIST0 * 2^-16) == 8192.0f
+    }
+    __syncthreads();
+    if (stop_after == 1) return;
+    u16 *s_ptr = s_big;  // the dl tile is dead
+    for (int k = tid; k < X_T * X_T; k += X_NT) {
+        const int r = k >> 7, c = k & (X_T - 1);
+        const int code = s_code[k];
+        int di, dj;
+        tap_decode(code, di, dj);
+        const u32 nr = (u32)(r + di), nc = (u32)(c + dj);
+        const bool inside = code < 16 && nr < (u32)X_T && nc < (u32)X_T;
+        s_ptr[k] = inside ? (u16)(nr * X_T + nc) : (u16)(k | 0x8000);
+    }
+    __syncthreads();
+    if (stop_after == 2) return;
+    // pointer doubling.  Each thread owns cells tid + 256 j and keeps the still-open ones as bits, so late
+    // rounds only touch what is left; two jumps per round.  Any pointer value read here is an ancestor of the
+    // cell (other threads only ever replace a pointer by a farther ancestor): races just speed things up.
+    {
+        u64 open = 0;
+#pragma unroll 8
+        for (int j = 0; j < X_T * X_T / X_NT; ++j) open |= (u64)(!(s_ptr[tid + X_NT * j] & 0x8000)) << j;
+        for (int round = 0; round < 16; ++round) {  // 4^16 > any in-tile chain
+            u64 m = open;
+            while (m) {
+                const int j = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int k = tid + X_NT * j;
+                int q = s_ptr[s_ptr[k]];  // s_ptr[k] has no flag: k is open
+                if (!(q & 0x8000)) q = s_ptr[q];
+                s_ptr[k] = (u16)q;
+                if (q & 0x8000) open &= ~(1ull << j);
+            }
+            if (!__syncthreads_or(open != 0)) break;
+        }
+    }
+    if (stop_after == 3) return;
+    for (int k = tid; k < X_T * X_T; k += X_NT) {
+        const int r = k >> 7, c = k & (X_T - 1);
+        const int gi = r0 + r, gj = c0 + c;
+        if (gi >= H || gj >= W) continue;
+        const int t = s_ptr[k] & 0x3FFF;  // terminal cell of k's in-tile chain
+        const int code = s_code[t];
+        const int tr = r0 + (t >> 7), tc = c0 + (t & (X_T - 1));
+        u32 e;
+        if (code == PAR_SRC) {
+            e = X_ROOT | (u32)(tr * W + tc);
+        } else if (code >= 16) {
+            e = X_NONE;
+        } else {
+            int di, dj;
+            tap_decode(code, di, dj);
+            e = (u32)min(max((tr + di) * W + tc + dj, 0), H * W - 1);  // clamp: a logic error must not become a wild access
+        }
+        exitp[fo + (size_t)gi * W + gj] = e;
+    }
+}
+
+// k_final: follow the exit pointers from tile to tile (a chain crosses few tiles), then label, gather, store.
+__global__ __launch_bounds__(256) void k_final(
+    const float *__restrict__ x, const u32 *__restrict__ exitp,
+    const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
+    const int *__restrict__ finfo, const float *__restrict__ vlist, const int *__restrict__ fflag, int H,
+    int W, int Wd, float *__restrict__ out_depth, int32_t *__restrict__ out_index,
+    int *__restrict__ frame_status) {
+    const int b = blockIdx.y;
+    if (!fflag[b]) return;
+    const size_t fo = (size_t)b * H * W;
+    const u32 *ef = exitp + fo;
+    const int N1 = H * W;
+    const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
+    constexpr int FB = 8;  // pixels per lane whose loads are in flight together
+    for (int pb = blockIdx.x * (256 * G_PPT) + threadIdx.x; pb < min(N1, (int)(blockIdx.x + 1) * 256 * G_PPT);
+         pb += 256 * FB) {
+        u32 e[FB];
+#pragma unroll
+        for (int u = 0; u < FB; ++u) e[u] = ef[min(pb + 256 * u, N1 - 1)];
+        for (int hop = 0; hop < MAX_HW_SUM; ++hop) {  // tile-to-tile hops, all FB chains in lock-step
+            bool open = false;
+#pragma unroll
+            for (int u = 0; u < FB; ++u) {
+                const bool mv = !(e[u] & X_ROOT) && e[u] != X_NONE;
+                const u32 nx = ef[mv ? e[u] : 0u];
+                e[u] = mv ? nx : e[u];
+                open |= mv;
+            }
+            if (!__any(open)) break;
+        }
+        int label[FB], q[FB];
+        u32 base[FB];
+        u64 word[FB];
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+            const bool root = e[u] & X_ROOT;
+            q[u] = root ? (int)(e[u] & ~X_ROOT) : 0;
+            const int i = q[u] / W;
+            const size_t w = ((size_t)b * H + i) * Wd + ((q[u] - i * W) >> 6);
+            base[u] = rowbase_s[(size_t)b * H + i] + wpre_s[w];
+            word[u] = srcbits[w];
+        }
+        float val[FB];
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+            const int i = q[u] / W;
+            label[u] = (e[u] & X_ROOT) ? source_rank(base[u], word[u], q[u] - i * W) : 0;
+            const int p = pb + 256 * u;
+            val[u] = (out_depth && p < N1) ? gather_depth(x + fo, vlist + fo, label[u], q[u], nval, misaligned, frame_status + b)
+                                          : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+            const int p = pb + 256 * u;
+            if (p >= N1) continue;
+            if (out_index) out_index[fo + p] = label[u];
+            if (out_depth) out_depth[fo + p] = val[u];
+        }
+    }
+}

@@ -1,0 +1,224 @@
+// dtfill_prepass.hpp -- k_mask, k_frame: bit words, compaction ranks, frame facts (every pass starts with these)
+// Part of libdtfill.so; included by dtfill.hip inside its anonymous namespace (one translation unit).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// k_mask: one wave per M_RPW image rows.  Source predicate exactly as tools.py:8, mask = (1.0 - x) > thr
+// (1 = fill, 0 = source); value predicate as tools.py:22, x > thr.  Per 64-pixel word: the two bit
+// words and the row-local exclusive popcount; per row: totals (+ "masks differ" in bit 31).
+// ------------------------------------------------------------------------------------------------
+constexpr int M_RPW = 1;  // image rows per wave in k_mask
+constexpr int M_KU = 8;   // 64-pixel steps whose loads are issued together (M_KU * M_RPW loads in flight per lane)
+
+__device__ __forceinline__ u32 wave_incl_sum(u32 v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_mask(const float *__restrict__ x, int H, int W, int Wd,
+                                              float src_thr, float val_thr, u64 *__restrict__ srcbits,
+                                              u64 *__restrict__ valbits, u16 *__restrict__ wpre_s,
+                                              u16 *__restrict__ wpre_v, u32 *__restrict__ rowcnt_s,
+                                              u32 *__restrict__ rowcnt_v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = (blockIdx.x * 4 + wave) * M_RPW, b = blockIdx.y;
+    if (i0 >= H) return;
+    u32 run_s[M_RPW], run_v[M_RPW], mis[M_RPW];
+#pragma unroll
+    for (int q = 0; q < M_RPW; ++q) run_s[q] = run_v[q] = mis[q] = 0;
+    // 64 words (4096 pixels) of every row per chunk: lane k ends up holding word k0 + k of each row, so the
+    // words and their prefix counts leave as ONE coalesced store per row and array
+    for (int k0 = 0; k0 < Wd; k0 += 64) {
+        const int nk = min(64, Wd - k0);
+        u64 ws[M_RPW], wv[M_RPW];
+#pragma unroll
+        for (int q = 0; q < M_RPW; ++q) ws[q] = wv[q] = 0;
+        for (int kb = 0; kb < nk; kb += M_KU) {  // M_KU word steps x M_RPW rows: all loads first, then the ballots
+            float v[M_KU][M_RPW];
+#pragma unroll
+            for (int u = 0; u < M_KU; ++u) {
+                const int j = (k0 + kb + u) * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < M_RPW; ++q) {
+                    const int i = min(i0 + q, H - 1);
+                    v[u][q] = (kb + u < nk && j < W) ? x[((size_t)b * H + i) * W + j] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < M_KU; ++u) {
+                const int k = kb + u;
+                const bool in = k < nk && (k0 + k) * 64 + lane < W;
+#pragma unroll
+                for (int q = 0; q < M_RPW; ++q) {
+                    const u64 sb = __ballot(in && !((1.0f - v[u][q]) > src_thr));
+                    const u64 vb = __ballot(in && (v[u][q] > val_thr));
+                    ws[q] = lane == k ? sb : ws[q];
+                    wv[q] = lane == k ? vb : wv[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < M_RPW; ++q) {
+            const u32 cs = __popcll(ws[q]), cv = __popcll(wv[q]);
+            const u32 is = wave_incl_sum(cs, lane), iv = wave_incl_sum(cv, lane);
+            mis[q] |= __any(ws[q] != wv[q]) ? 1u : 0u;
+            if (lane < nk && i0 + q < H) {
+                const size_t wi = ((size_t)b * H + i0 + q) * Wd + k0 + lane;
+                srcbits[wi] = ws[q];
+                valbits[wi] = wv[q];
+                wpre_s[wi] = (u16)(run_s[q] + is - cs);
+                wpre_v[wi] = (u16)(run_v[q] + iv - cv);
+            }
+            run_s[q] += __shfl(is, 63);
+            run_v[q] += __shfl(iv, 63);
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < M_RPW; ++q)
+            if (i0 + q < H) {
+                rowcnt_s[(size_t)b * H + i0 + q] = run_s[q];
+                rowcnt_v[(size_t)b * H + i0 + q] = run_v[q] | (mis[q] ? 0x80000000u : 0u);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_frame: one workgroup per frame.  Exclusive scan of the row counts = raster rank of the first
+// source / value pixel of every row: cv2's label init (k=1; every zero pixel gets k++) and numpy's
+// boolean compaction x[with_value] (tools.py:24).  The value list is only materialised when the two
+// masks differ somewhere in the frame.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, const u64 *__restrict__ valbits,
+                                               const u16 *__restrict__ wpre_v,
+                                               const u32 *__restrict__ rowcnt_s,
+                                               const u32 *__restrict__ rowcnt_v, int H, int W, int Wd,
+                                               u32 *__restrict__ rowbase_s, u32 *__restrict__ rowbase_v,
+                                               int *__restrict__ finfo, float *__restrict__ vlist,
+                                               int *__restrict__ fflag, int *__restrict__ fflag2,
+                                               int *__restrict__ frame_status, int force_general) {
+    __shared__ u32 s_ws[4], s_wv[4];
+    __shared__ int s_mis, s_dlb;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 *cs_ = rowcnt_s + (size_t)b * H, *cv_ = rowcnt_v + (size_t)b * H;
+    if (tid == 0) s_dlb = 0;
+    u32 *bs_ = rowbase_s + (size_t)b * H, *bv_ = rowbase_v + (size_t)b * H;
+    if (tid == 0) s_mis = 0;
+    __syncthreads();
+    u32 run_s = 0, run_v = 0;
+    int mis = 0;
+    for (int base = 0; base < H; base += 256) {
+        const int i = base + tid;
+        u32 cs = 0, cv = 0;
+        if (i < H) {
+            cs = cs_[i];
+            cv = cv_[i];
+            mis |= (int)(cv >> 31);
+            cv &= 0x7FFFFFFFu;
+        }
+        u32 is = cs, iv = cv;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            u32 ts = __shfl_up(is, off), tv = __shfl_up(iv, off);
+            if (lane >= off) {
+                is += ts;
+                iv += tv;
+            }
+        }
+        if (lane == 63) {
+            s_ws[wave] = is;
+            s_wv[wave] = iv;
+        }
+        __syncthreads();
+        u32 ps = 0, pv = 0, ts = 0, tv = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < wave) {
+                ps += s_ws[k];
+                pv += s_wv[k];
+            }
+            ts += s_ws[k];
+            tv += s_wv[k];
+        }
+        if (i < H) {
+            bs_[i] = run_s + ps + is - cs;
+            bv_[i] = run_v + pv + iv - cv;
+        }
+        run_s += ts;
+        run_v += tv;
+        __syncthreads();
+    }
+    if (mis) atomicOr(&s_mis, 1);
+    // Lower bound of the largest distance in the frame from runs of rows without any source: a run of k
+    // empty rows forces d >= ceil(k/2) in its middle row, d >= k at the border row if it touches the top or
+    // bottom edge.  Each thread looks at the run ENDING at its rows (cheap: the counts are in L2).
+    {
+        // "row has no source" as bits in LDS (H <= 8191 -> 256 words), so walking a run costs LDS reads only
+        __shared__ u32 s_empty[256];
+        s_empty[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < H; i += 256)
+            if (cs_[i] == 0) atomicOr(&s_empty[i >> 5], 1u << (i & 31));
+        __syncthreads();
+        auto empty = [&](int i) { return (s_empty[i >> 5] >> (i & 31)) & 1u; };
+        int dlb = 0;
+        for (int i = tid; i < H; i += 256) {
+            if (!empty(i) || (i + 1 < H && empty(i + 1))) continue;  // not the last row of a run
+            int k = 1;
+            while (i - k >= 0 && empty(i - k)) ++k;
+            const bool edge = (i - k < 0) || (i + 1 >= H);
+            dlb = max(dlb, (i - k < 0 && i + 1 >= H) ? BIG : edge ? k : (k + 1) / 2);
+        }
+        if (dlb) atomicMax(&s_dlb, dlb);
+    }
+    __syncthreads();
+    const int misaligned = s_mis;
+    if (tid == 0) {
+        finfo[b * FI_STRIDE + FI_NSRC] = (int)run_s;
+        finfo[b * FI_STRIDE + FI_NVAL] = (int)run_v;
+        finfo[b * FI_STRIDE + FI_MISALIGNED] = misaligned;
+        finfo[b * FI_STRIDE + FI_DLB] = s_dlb;
+        fflag[b] = 0;                       // set by k_fused<16>: the frame needs a wider halo
+        fflag2[b] = force_general ? 1 : 0;  // set by k_fused<32>: the frame needs the general path
+        frame_status[b] = force_general ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
+    }
+    if (misaligned) {
+        // rare path: scatter x at value pixels into the compacted value list
+        const float *xf = x + (size_t)b * H * W;
+        float *vl = vlist + (size_t)b * H * W;
+        const int nwords = H * Wd;
+        for (int w = tid; w < nwords; w += 256) {
+            u64 vb = valbits[(size_t)b * nwords + w];
+            const int i = w / Wd, j0 = (w - i * Wd) * 64;
+            u32 k = bv_[i] + wpre_v[(size_t)b * nwords + w];
+            while (vb) {
+                const int bit = __ffsll((long long)vb) - 1;
+                vb &= vb - 1;
+                vl[k++] = xf[(size_t)i * W + j0 + bit];
+            }
+        }
+    }
+}
+
+// label of the source at (i, j): 1 + number of sources before it in raster order
+__device__ __forceinline__ int source_rank(u32 base, u64 word, int j) {
+    return (int)base + __popcll(word & ((1ull << (j & 63)) - 1ull)) + 1;
+}
+
+// gather depth_list[label-1] with numpy's index semantics (tools.py:26)
+__device__ __forceinline__ float gather_depth(const float *__restrict__ xf, const float *__restrict__ vlf,
+                                              int label, int src_pixel, int nval, int misaligned,
+                                              int *frame_status_b) {
+    int idx = label - 1;
+    if (idx < 0) idx += nval;  // numpy: index -1 wraps to the last element
+    if (idx < 0 || idx >= nval) {
+        atomicOr(frame_status_b, DTFILL_FRAME_INDEX_ERROR);
+        return nanf("");
+    }
+    if (misaligned) return vlf[idx];
+    return xf[src_pixel];  // masks agree: the label-th value IS the source pixel's own depth
+}

@@ -53,7 +53,7 @@ def test_product_does_not_import_oracle():
     pkgdir = os.path.join(ROOT, "distancetransform-depthcompletion_amd")
     for dp, _, files in os.walk(pkgdir):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
+            if f.endswith((".py", ".hip", ".h", ".hpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "liboracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
 
