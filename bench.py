@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_PIXEL = 16   # read f32 depth, write f32 depth + f32 distance + i32 index
 
 
-def cpu_baseline(x, budget_s=12.0):
+def cpu_baseline(x, cpu_seconds=20.0):
     """Oracle (CPU port of the reference path) over frames of x, one frame per task on a thread
     pool over all host cores (ctypes releases the GIL; OpenCV's labels transform is serial per
     frame, so frames are the unit of parallelism)."""
@@ -53,7 +53,7 @@ def cpu_baseline(x, budget_s=12.0):
     t0 = time.perf_counter()
     O.fill_batch(x[:1])
     per_frame = time.perf_counter() - t0
-    n = int(max(cores, min(50 * cores, budget_s * cores / max(per_frame, 1e-4))))
+    n = int(max(cores, cpu_seconds / max(per_frame, 1e-4)))  # ~cpu_seconds of single-core work in total
     frames = [x[i % B : i % B + 1] for i in range(n)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
