@@ -11,7 +11,7 @@ or through the `dtfill_amd` alias module at the repository root.
 from . import _lib
 from ._lib import METRICS, DtfillError, build, load
 from .sharding import shard_range, gather_frames, fill_sharded
-from .tools import DT_complete_batch, Distance_Transform, nearest_point, outlier_removal
+from .tools import DT_complete_batch, Distance_Transform, generate_multi_channel, nearest_point, outlier_removal
 
 
 def __getattr__(name):
@@ -25,6 +25,6 @@ def __getattr__(name):
 
 
 __all__ = [
-    "nearest_point", "DT_complete_batch", "Distance_Transform", "outlier_removal", "fill", "DtFill",
+    "nearest_point", "DT_complete_batch", "Distance_Transform", "outlier_removal", "generate_multi_channel", "fill", "DtFill",
     "shard_range", "gather_frames", "fill_sharded", "build", "load", "METRICS", "DtfillError",
 ]

@@ -33,6 +33,7 @@ SYMBOLS = (
     "dtfill_kernel_name",
     "dtfill_batch_timed",
     "dtfill_outlier_removal",
+    "dtfill_generate_multi_channel",
 )
 
 _lib = None
@@ -86,6 +87,8 @@ def load():
     L.dtfill_batch_timed.restype = ci
     L.dtfill_outlier_removal.argtypes = [vp, ci, ci, ci, vp, vp]
     L.dtfill_outlier_removal.restype = ci
+    L.dtfill_generate_multi_channel.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
+    L.dtfill_generate_multi_channel.restype = ci
     _lib = L
     return L
 

@@ -66,6 +66,7 @@ namespace {
 #include "dtfill_general.hpp"   // also k_colscan<true> used by the l2 pass
 #include "dtfill_l2.hpp"
 #include "dtfill_outlier.hpp"
+#include "dtfill_gmc.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -286,6 +287,28 @@ int dtfill_outlier_removal(const float *x, int B, int H, int W, float *out, void
     if (B < 1 || H < 4 || W < 4 || (long long)B * H * W >= (1ll << 31) || B > 65535) return DTFILL_ERR_SHAPE;
     k_outlier<<<dim3((W + O_TW - 1) / O_TW, (H + O_TH - 1) / O_TH, B), 256, 0, static_cast<hipStream_t>(stream)>>>(
         x, H, W, out);
+    return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
+}
+
+int dtfill_generate_multi_channel(const float *data, const float *mask, int B, int H, int W, int table_size,
+                                  int scale_num, float *out2, float *out3, float *out4, void *stream) {
+    if (!data || !mask) return DTFILL_ERR_NULL;
+    if (B < 1 || H < 1 || W < 1 || (long long)B * H * W >= (1ll << 31) || B > 65535) return DTFILL_ERR_SHAPE;
+    if (table_size < 1 || (table_size & 1) == 0 || (table_size - 1) / 2 > GM_MAXHALF || scale_num < 1 || scale_num > 4)
+        return DTFILL_ERR_SHAPE;
+    float *outs[3] = {out2, out3, out4};
+    for (int k = 0; k < scale_num - 1; ++k)
+        if (!outs[k]) return DTFILL_ERR_NULL;
+    const int half = (table_size - 1) / 2;
+    const size_t lds = (size_t)2 * (GM_TH + 2 * half) * (GM_TW + 2 * half) * sizeof(float);
+    const dim3 grid((W + GM_TW - 1) / GM_TW, (H + GM_TH - 1) / GM_TH, B);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float *src = data, *msk = mask;
+    for (int k = 0; k < scale_num - 1; ++k) {
+        k_gmc<<<grid, 256, lds, st>>>(src, msk, H, W, table_size, outs[k]);
+        src = outs[k];
+        msk = nullptr;  // the next step's mask is (previous output > 0.001)
+    }
     return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
 

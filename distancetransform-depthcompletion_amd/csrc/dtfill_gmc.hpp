@@ -1,0 +1,52 @@
+// dtfill_gmc.hpp -- k_gmc: one step of generate_multi_channel(), net.py:83-122
+// Part of libdtfill.so; included by dtfill.hip inside its anonymous namespace (one translation unit).
+#pragma once
+
+// One step of the reference's windowed nearest fill: over the ts x ts window (zero padding, as
+// tf.image.extract_patches(padding='SAME')), s = mask * w with w = ts - |di| - |dj| (net.py:71-81);
+// out = (sum of the inputs at the positions where s equals the window maximum) / (1e-6 + their count)
+// (net.py:91-93).  mask == nullptr: the mask is (data > 0.001f), what the reference feeds to the next step
+// (net.py:95-96).  float32; the sum runs over the taps in row-major order, a new maximum restarts it, so
+// the additions are exactly those of "sum over the selected taps in order".
+// One block per 16 x 64 tile; data and mask tiles with a (ts-1)/2 halo in LDS.
+constexpr int GM_TH = 16, GM_TW = 64, GM_MAXHALF = 7;
+
+__global__ __launch_bounds__(256) void k_gmc(const float *__restrict__ data, const float *__restrict__ mask, int H,
+                                             int W, int ts, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float s_gm[];
+    const int half = (ts - 1) / 2;
+    const int PW = GM_TW + 2 * half, PH = GM_TH + 2 * half;
+    float *s_d = s_gm, *s_m = s_gm + PH * PW;
+    const int b = blockIdx.z, r0 = blockIdx.y * GM_TH, c0 = blockIdx.x * GM_TW;
+    const size_t fo = (size_t)b * H * W;
+    for (int k = threadIdx.x; k < PH * PW; k += 256) {
+        const int r = k / PW, c = k - r * PW;
+        const int gi = r0 + r - half, gj = c0 + c - half;
+        const bool in = gi >= 0 && gi < H && gj >= 0 && gj < W;
+        const float v = in ? data[fo + (size_t)gi * W + gj] : 0.0f;
+        s_d[k] = v;
+        s_m[k] = in ? (mask ? mask[fo + (size_t)gi * W + gj] : (v > 0.001f ? 1.0f : 0.0f)) : 0.0f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < GM_TH * GM_TW; k += 256) {
+        const int r = k / GM_TW, c = k - r * GM_TW;
+        const int gi = r0 + r, gj = c0 + c;
+        if (gi >= H || gj >= W) continue;
+        float mx = 0.0f, acc = 0.0f, cnt = 0.0f;
+        // pass 1: the window maximum of mask * w (max over exact small products: order does not matter)
+        for (int i = 0; i < ts; ++i)
+            for (int j = 0; j < ts; ++j) {
+                const float w = (float)(ts - abs(i - half) - abs(j - half));
+                mx = fmaxf(mx, s_m[(r + i) * PW + c + j] * w);
+            }
+        // pass 2: sum and count of the positions that reach it, in tap order
+        for (int i = 0; i < ts; ++i)
+            for (int j = 0; j < ts; ++j) {
+                const float w = (float)(ts - abs(i - half) - abs(j - half));
+                const bool sel = s_m[(r + i) * PW + c + j] * w == mx;
+                acc = sel ? __fadd_rn(acc, s_d[(r + i) * PW + c + j]) : acc;
+                cnt += sel ? 1.0f : 0.0f;
+            }
+        out[fo + (size_t)gi * W + gj] = __fdiv_rn(acc, __fadd_rn(0.000001f, cnt));
+    }
+}

@@ -148,6 +148,25 @@ def outlier_removal_device(x):
     return out
 
 
+def generate_multi_channel_device(data, mask, table_size=7, scale_num=4):
+    """net.py:83-122 on the device.  data, mask: contiguous float32 CUDA tensors [B,H,W].
+    Returns (lidar_1, lidar_2, lidar_3, lidar_4) with None beyond scale_num, like the reference."""
+    _require_gpu()
+    for t in (data, mask):
+        if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 3 or not t.is_contiguous():
+            raise ValueError("data and mask must be contiguous float32 CUDA tensors [B,H,W]")
+    if data.shape != mask.shape:
+        raise ValueError("data and mask shapes differ")
+    B, H, W = data.shape
+    outs = [torch.empty_like(data) for _ in range(scale_num - 1)]
+    ptrs = [o.data_ptr() for o in outs] + [None] * (4 - scale_num)
+    with torch.cuda.device(data.device):
+        _lib.check(_lib.load().dtfill_generate_multi_channel(
+            data.data_ptr(), mask.data_ptr(), B, H, W, table_size, scale_num, ptrs[0], ptrs[1], ptrs[2],
+            torch.cuda.current_stream(data.device).cuda_stream))
+    return tuple([data] + outs + [None] * (4 - scale_num))
+
+
 _default_ops = {}
 
 

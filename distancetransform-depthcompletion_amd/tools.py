@@ -79,3 +79,19 @@ def outlier_removal(lidar):
         raise ValueError("outlier_removal expects an array squeezable to [H,W], got shape %s" % (np.shape(lidar),))
     xd = torch.from_numpy(np.ascontiguousarray(x[None])).to(_device.default_op().device)
     return _device.outlier_removal_device(xd)[0].cpu().numpy()
+
+
+def generate_multi_channel(lidar_data, lidar_mask, table_size=7, scale_num=4):
+    """net.py:83-122 as a numpy function: lidar_data, lidar_mask [B,H,W,1] -> (lidar_1, .., lidar_4), each
+    [B,H,W,1] float32, None beyond scale_num (the reference returns TF tensors of the same shapes)."""
+    import torch
+
+    d = _as_f32_frames(lidar_data)
+    m = _as_f32_frames(lidar_mask)
+    if d.ndim != 4 or d.shape[-1] != 1 or m.shape != d.shape:
+        raise ValueError("generate_multi_channel expects lidar_data and lidar_mask of shape [B,H,W,1]")
+    dev = _device.default_op().device
+    dd = torch.from_numpy(np.ascontiguousarray(d[..., 0])).to(dev)
+    mm = torch.from_numpy(np.ascontiguousarray(m[..., 0])).to(dev)
+    outs = _device.generate_multi_channel_device(dd, mm, table_size, scale_num)
+    return tuple(None if o is None else o.cpu().numpy()[..., None] for o in outs)

@@ -116,6 +116,18 @@ int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float
  */
 int dtfill_outlier_removal(const float *x, int B, int H, int W, float *out, void *stream);
 
+/*
+ * generate_multi_channel() of the reference's models, solution_DeepNet/net.py:83-122 (weights
+ * create_weight_matrix, net.py:71-81): the in-network windowed nearest fill.  Step k: over the
+ * table_size^2 window (zero padding), s = mask * (table_size - |di| - |dj|); out = sum of the inputs where s
+ * equals its window maximum / (1e-6 + their count); the next step's mask is (out > 0.001).
+ * data, mask: float32 [B,H,W] (the reference's [B,H,W,1]); out2/out3/out4: the reference's lidar_2..4
+ * (those beyond scale_num may be NULL); lidar_1 is the input itself.  table_size odd, <= 15; scale_num 1..4.
+ * float32; the window sum is accumulated in tap (row-major) order.
+ */
+int dtfill_generate_multi_channel(const float *data, const float *mask, int B, int H, int W, int table_size,
+                                  int scale_num, float *out2, float *out3, float *out4, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

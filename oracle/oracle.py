@@ -112,6 +112,44 @@ def Distance_Transform(lidar, src_thr=0.001, val_thr=0.1):
     return values[labels.reshape(1, -1) - 1].reshape(frame.shape)
 
 
+def generate_multi_channel(lidar_data, lidar_mask, table_size=7, scale_num=4):
+    """net.py:83-122 restated (the in-network windowed nearest fill every model class
+    carries, weights from create_weight_matrix net.py:71-81).  TensorFlow is absent here: PARITY UNPINNED.
+    One step: over the table_size^2 window (zero padding, extract_patches padding='SAME'), s = mask * w with
+    w = table_size - |di| - |dj|; the output is the sum of the inputs at the positions where s equals its
+    window maximum, divided by (1e-6 + their count) -- including the all-zero case, where every position
+    (padding too) ties at 0.  The next step's mask is (output > 0.001).  float32 throughout; the window sum
+    is accumulated in tap (row-major) order -- TF's reduction order is unspecified, so against a real TF
+    this is exact only up to float32 summation order.
+    lidar_data, lidar_mask: [B,H,W,1] (or [B,H,W]).  Returns (lidar_1, .., lidar_4) like the reference,
+    None for the scales beyond scale_num."""
+    data = np.asarray(lidar_data, np.float32)
+    mask = np.asarray(lidar_mask, np.float32)
+    squeeze_c = data.ndim == 4
+    if squeeze_c:
+        data, mask = data[..., 0], mask[..., 0]
+    half = (table_size - 1) // 2
+    outs = [np.asarray(lidar_data, np.float32)]
+    for _ in range(scale_num - 1):
+        B, H, W = data.shape
+        pd = np.pad(data, ((0, 0), (half, half), (half, half)))
+        pm = np.pad(mask, ((0, 0), (half, half), (half, half)))
+        taps = [(i, j, np.float32(table_size - abs(i - half) - abs(j - half))) for i in range(table_size) for j in range(table_size)]
+        mx = np.zeros((B, H, W), np.float32)
+        for i, j, w in taps:
+            mx = np.maximum(mx, pm[:, i : i + H, j : j + W] * w)
+        acc = np.zeros((B, H, W), np.float32)
+        cnt = np.zeros((B, H, W), np.float32)
+        for i, j, w in taps:
+            sel = (pm[:, i : i + H, j : j + W] * w) == mx
+            acc = np.where(sel, (acc + pd[:, i : i + H, j : j + W]).astype(np.float32), acc)
+            cnt = cnt + sel.astype(np.float32)
+        data = (acc / (np.float32(0.000001) + cnt)).astype(np.float32)
+        mask = (data > np.float32(0.001)).astype(np.float32)
+        outs.append(data[..., None] if squeeze_c else data)
+    return tuple(outs + [None] * (4 - len(outs)))
+
+
 _DIAMOND7 = np.array([[abs(i - 3) + abs(j - 3) <= 3 for j in range(7)] for i in range(7)])
 
 

@@ -388,6 +388,23 @@ def test_concurrent_streams_and_threads(pkg, oracle):
     assert not errors, errors
 
 
+def test_generate_multi_channel_vs_oracle(pkg, oracle):
+    """net.py:83-122.  Same float32 operations in the same order as the restated oracle, so
+    equality is exact (against a real TF the sum order is the only freedom; tolerance 1e-6 relative there)."""
+    rng = np.random.default_rng(21)
+    for (B, H, W), ts, sn in [((2, 64, 200), 7, 4), ((1, 256, 1216), 7, 4), ((1, 9, 11), 5, 3), ((3, 5, 4), 3, 2)]:
+        x = np.where(rng.random((B, H, W, 1)) < 0.05, rng.uniform(1, 80, (B, H, W, 1)), 0).astype(np.float32)
+        m = (x > 0.1).astype(np.float32)
+        got = pkg.generate_multi_channel(x, m, ts, sn)
+        want = oracle.generate_multi_channel(x, m, ts, sn)
+        assert len(got) == 4
+        for g, w in zip(got, want):
+            assert (g is None) == (w is None)
+            if g is not None:
+                assert g.shape == x.shape and g.dtype == np.float32
+                assert np.array_equal(g, w)
+
+
 def test_shape_errors(gpu_op, pkg):
     import torch
 
