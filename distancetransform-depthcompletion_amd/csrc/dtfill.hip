@@ -305,7 +305,12 @@ int dtfill_generate_multi_channel(const float *data, const float *mask, int B, i
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float *src = data, *msk = mask;
     for (int k = 0; k < scale_num - 1; ++k) {
-        k_gmc<<<grid, 256, lds, st>>>(src, msk, H, W, table_size, outs[k]);
+        if (table_size == 7 && msk)
+            k_gmc7<false><<<grid, 256, 0, st>>>(src, msk, H, W, outs[k]);
+        else if (table_size == 7)
+            k_gmc7<true><<<grid, 256, 0, st>>>(src, nullptr, H, W, outs[k]);
+        else
+            k_gmc<<<grid, 256, lds, st>>>(src, msk, H, W, table_size, outs[k]);
         src = outs[k];
         msk = nullptr;  // the next step's mask is (previous output > 0.001)
     }

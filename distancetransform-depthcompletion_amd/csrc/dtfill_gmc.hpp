@@ -11,6 +11,52 @@
 // One block per 16 x 64 tile; data and mask tiles with a (ts-1)/2 halo in LDS.
 constexpr int GM_TH = 16, GM_TW = 64, GM_MAXHALF = 7;
 
+// table_size 7 (every model of the reference), compile-time unrolled, ONE pass over the 49 taps: a new window
+// maximum restarts sum and count, an equal value extends them -- the additions performed are exactly "sum
+// over the selected taps in tap order", as in the two-pass form below.  DERIVED: the mask is data > 0.001
+// (steps 2 and 3), so only the data tile is staged.
+template <bool DERIVED>
+__global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, const float *__restrict__ mask, int H,
+                                              int W, float *__restrict__ out) {
+    constexpr int half = 3, PW = GM_TW + 6, PH = GM_TH + 6;
+    __shared__ float s_d[PH * PW];
+    __shared__ float s_m[DERIVED ? 1 : PH * PW];
+    const int b = blockIdx.z, r0 = blockIdx.y * GM_TH, c0 = blockIdx.x * GM_TW;
+    const size_t fo = (size_t)b * H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < PH; r += 4) {
+        const int gi = r0 + r - half;
+        for (int c = lane; c < PW; c += 64) {
+            const int gj = c0 + c - half;
+            const bool in = gi >= 0 && gi < H && gj >= 0 && gj < W;
+            s_d[r * PW + c] = in ? data[fo + (size_t)gi * W + gj] : 0.0f;
+            if (!DERIVED) s_m[r * PW + c] = in ? mask[fo + (size_t)gi * W + gj] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int c = lane;
+    for (int r = wave; r < GM_TH; r += 4) {
+        const int gi = r0 + r, gj = c0 + c;
+        if (gi >= H || gj >= W) continue;
+        float mx = 0.0f, acc = 0.0f, cnt = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const float w = (float)(7 - (i < 3 ? 3 - i : i - 3) - (j < 3 ? 3 - j : j - 3));
+                const float v = s_d[(r + i) * PW + c + j];
+                const float m = DERIVED ? (v > 0.001f ? 1.0f : 0.0f) : s_m[(r + i) * PW + c + j];
+                const float sv = m * w;
+                const bool gt = sv > mx, eq = sv == mx;
+                acc = gt ? v : (eq ? __fadd_rn(acc, v) : acc);
+                cnt = gt ? 1.0f : (eq ? cnt + 1.0f : cnt);
+                mx = gt ? sv : mx;
+            }
+        }
+        out[fo + (size_t)gi * W + gj] = __fdiv_rn(acc, __fadd_rn(0.000001f, cnt));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gmc(const float *__restrict__ data, const float *__restrict__ mask, int H,
                                              int W, int ts, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float s_gm[];
