@@ -222,7 +222,7 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     mark();
     k_colscan<true><<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, nullptr, H, W, Wd, (H + G_NCH - 1) / G_NCH, c.gu, c.g);
     mark();
-    k_l2row<<<dim3((H * W + 255) / 256, B), 256, 0, st>>>(x, c.g, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W,
+    k_l2row<<<dim3(H, B), 256, (size_t)W * sizeof(u16), st>>>(x, c.g, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W,
                                                          Wd, out_depth, out_dt, out_index, status);
     mark();
     return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;

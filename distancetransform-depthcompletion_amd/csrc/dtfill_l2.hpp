@@ -15,12 +15,18 @@ __global__ __launch_bounds__(256) void k_l2row(const float *__restrict__ x, cons
                                                const float *__restrict__ vlist, int H, int W, int Wd,
                                                float *__restrict__ out_depth, float *__restrict__ out_dt,
                                                int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
-    const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= H * W) return;
+    // one block per image row: the row of g is staged in LDS once, every pixel's outward search reads it there
+    extern __shared__ __attribute__((aligned(16))) u16 s_grow[];
+    const int b = blockIdx.y, i = blockIdx.x;
     const size_t fo = (size_t)b * H * W;
-    const int i = p / W, j = p - i * W;
-    const u16 *grow = g + fo + (size_t)i * W;
+    {
+        const u16 *grow_g = g + fo + (size_t)i * W;
+        for (int k = threadIdx.x; k < W; k += 256) s_grow[k] = grow_g[k];
+    }
+    __syncthreads();
+    const u16 *grow = s_grow;
+    for (int j = threadIdx.x; j < W; j += 256) {
+    const int p = i * W + j;
     // best candidate: key = (d2, source row, source column), lexicographic
     long long best = 0x7FFFFFFFFFFFFFFFll;
     int bestd2 = 0x7FFFFFFF;
@@ -69,4 +75,5 @@ __global__ __launch_bounds__(256) void k_l2row(const float *__restrict__ x, cons
     if (out_depth)
         out_depth[fo + p] = gather_depth(x + fo, vlist + fo, label, q, finfo[b * FI_STRIDE + FI_NVAL],
                                          finfo[b * FI_STRIDE + FI_MISALIGNED], frame_status + b);
+    }
 }
