@@ -109,3 +109,52 @@ def nearest_point(x, src_thr=0.1):
     label, _ = resolve(code, src)
     dt = np.where(d >= BIG // 2, np.float32(8192.0), d.astype(np.float32)).astype(np.float32)
     return dt, label
+
+
+def nearest_point_levels(x, src_thr=0.1, max_level=None):
+    """The LEVEL-SYNCHRONOUS form the fused kernels run, for one whole frame:
+    E_t = pixels at distance t, L_t = the live ones; forward taps offer L_{t-w}, backward taps E_{t-w};
+    first tap in cv2 order wins; roots are propagated level by level.  Returns (dt, lbl)."""
+    x = np.asarray(x, np.float32)
+    src = ~((np.float32(1.0) - x) > np.float32(src_thr))
+    H, W = src.shape
+    if not src.any():
+        return np.full((H, W), 8192.0, np.float32), np.zeros((H, W), np.int32)
+
+    def shift(P, di, dj):  # Q[q] = P[q + (di, dj)], zero outside
+        Q = np.zeros_like(P)
+        r0, r1 = max(0, -di), min(H, H - di)
+        c0, c1 = max(0, -dj), min(W, W - dj)
+        if r0 < r1 and c0 < c1:
+            Q[r0:r1, c0:c1] = P[r0 + di : r1 + di, c0 + dj : c1 + dj]
+        return Q
+
+    Z = np.zeros((H, W), bool)
+    D = src.copy()
+    E, L = {0: src.copy()}, {0: src.copy()}
+    rank = np.cumsum(src.ravel()).reshape(H, W)
+    label = np.where(src, rank, 0).astype(np.int64)
+    dist = np.zeros((H, W), np.int64)
+    t = 0
+    while not D.all():
+        t += 1
+        Et = (shift(D, 1, 0) | shift(D, -1, 0) | shift(D, 0, 1) | shift(D, 0, -1)) & ~D
+        taken = Z.copy()
+        new_label = label.copy()
+        for di, dj, w in FWD:
+            cand = shift(L.get(t - w, Z), di, dj) & Et
+            sel = cand & ~taken
+            taken |= cand
+            new_label = np.where(sel, shift(label, di, dj), new_label)
+        Lt = taken
+        takenb = ~(Et & ~Lt)
+        for di, dj, w in FWD:
+            cand = shift(E.get(t - w, Z), -di, -dj)
+            sel = cand & ~takenb
+            takenb |= cand
+            new_label = np.where(sel, shift(label, -di, -dj), new_label)
+        label = new_label
+        dist[Et] = t
+        E[t], L[t] = Et, Lt
+        D = D | Et
+    return dist.astype(np.float32), label.astype(np.int32)

@@ -46,3 +46,39 @@ def test_full_size(oracle, pkg, name):
     synth = importlib.import_module(pkg.__name__ + ".synth")
     x = synth.make(name, B=1)[0]
     _check(oracle, x)
+
+
+def test_level_form_matches_oracle(oracle):
+    """The level-synchronous form (what k_fused runs) on whole frames, incl. tie-heavy lattices."""
+    rng = np.random.default_rng(77)
+    frames = []
+    for _ in range(150):
+        H, W = int(rng.integers(1, 28)), int(rng.integers(1, 34))
+        frames.append(np.where(rng.random((H, W)) < rng.choice([0.02, 0.1, 0.4]), 5.0, 0.0).astype(np.float32))
+    lat = np.zeros((25, 31), np.float32)
+    lat[::6, ::5] = 2.0
+    frames.append(lat)
+    for x in frames:
+        dt0, l0 = oracle.cv_distance_transform_with_labels((x < 0.9).astype(np.uint8))
+        dt1, l1 = PM.nearest_point_levels(x)
+        assert np.array_equal(dt0, dt1) and np.array_equal(l0, l1)
+
+
+def test_hypothesis_arbitrary_masks(oracle):
+    """Property test: for ARBITRARY source masks (not just i.i.d. ones) both parallel formulations equal
+    the sequential two-pass chamfer, distances and labels."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+
+    @settings(max_examples=150, deadline=None, derandomize=True)
+    @given(hnp.arrays(np.bool_, st.tuples(st.integers(1, 14), st.integers(1, 18))))
+    def check(src):
+        x = np.where(src, np.float32(3.0), np.float32(0.0))
+        dt0, l0 = oracle.cv_distance_transform_with_labels((~src).astype(np.uint8))
+        dt1, l1 = PM.nearest_point(x)
+        dt2, l2 = PM.nearest_point_levels(x)
+        assert np.array_equal(dt0, dt1) and np.array_equal(l0, l1)
+        assert np.array_equal(dt0, dt2) and np.array_equal(l0, l2)
+
+    check()
