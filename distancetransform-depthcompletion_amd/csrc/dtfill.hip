@@ -121,8 +121,8 @@ Carve carve(void *ws, int B, int H, int W) {
 }
 
 bool shape_ok(int B, int H, int W) {
-    return B >= 1 && H >= 1 && W >= 1 && (long long)H + W - 2 < MAX_HW_SUM &&
-           (long long)B * H * W < (1ll << 31);
+    return B >= 1 && B <= 65535 && H >= 1 && W >= 1 && (long long)H + W - 2 < MAX_HW_SUM &&
+           (long long)B * H * W < (1ll << 31);  // B is a grid dimension; pixel indices are 32-bit
 }
 
 constexpr int NK_L1 = 8;
@@ -248,7 +248,7 @@ const char *dtfill_strerror(int code) {
     switch (code) {
         case DTFILL_OK: return "ok";
         case DTFILL_ERR_NULL: return "null input, workspace, or no output requested";
-        case DTFILL_ERR_SHAPE: return "bad shape: need B,H,W >= 1, H+W-2 < 8192 and B*H*W < 2^31";
+        case DTFILL_ERR_SHAPE: return "bad shape: need 1 <= B <= 65535, H,W >= 1, H+W-2 < 8192 and B*H*W < 2^31";
         case DTFILL_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
         case DTFILL_ERR_METRIC: return "unknown metric";
         case DTFILL_ERR_LAUNCH: return "HIP kernel launch failed";

@@ -43,7 +43,7 @@ extern "C" {
 /* return codes */
 #define DTFILL_OK               0
 #define DTFILL_ERR_NULL        -1 /* x, workspace or every output is NULL */
-#define DTFILL_ERR_SHAPE       -2 /* B,H,W < 1, or H+W-2 >= 8192 (cv2's Q16 INIT_DIST0 range) */
+#define DTFILL_ERR_SHAPE       -2 /* B,H,W < 1, B > 65535, B*H*W >= 2^31, or H+W-2 >= 8192 (cv2's Q16 INIT_DIST0 range) */
 #define DTFILL_ERR_WORKSPACE   -3 /* ws_bytes < dtfill_workspace_bytes() or workspace not 256-B aligned */
 #define DTFILL_ERR_METRIC      -4 /* unknown metric */
 #define DTFILL_ERR_LAUNCH      -5 /* a HIP launch failed (hipGetLastError) */

@@ -33,6 +33,7 @@ def test_host_side_entry_points(pkg):
     assert L.dtfill_workspace_bytes(0, 352, 1216, 0) == 0
     assert L.dtfill_workspace_bytes(1, 5000, 5000, 0) == 0  # beyond cv2's Q16 distance range
     assert L.dtfill_workspace_bytes(1, 8, 8, 99) == 0
+    assert L.dtfill_workspace_bytes(70000, 4, 4, 0) == 0  # B is a grid dimension
     nk = L.dtfill_num_kernels(0)
     assert nk >= 1 and all(L.dtfill_kernel_name(0, k) for k in range(nk))
 
