@@ -76,6 +76,107 @@ __device__ __forceinline__ void ring_store3(u32 *__restrict__ ring, int slot, in
     for (int i = 0; i < F_HW; ++i) p[i] = w[i];
 }
 
+// P3 of the fused pass as a function of the staged window (s_par byte codes, s_sb / s_rk rank words): tile
+// pixels walk to their sources in lock-step, d, rank -> label, gather, store.  Returns whether some tile pixel
+// was undecided.  NT = threads of the calling block.
+template <int FR, int NT>
+__device__ __forceinline__ bool fused_walk_epilogue(
+    const u8 *__restrict__ s_par, const u32 *__restrict__ s_sb, const u32 *__restrict__ s_rk, int b, int H, int W,
+    int th, int tw, int r0, int c0, int wr0, int wc0, int ra, int rb, int ca, int cb, int w0,
+    const float *__restrict__ x, const float *__restrict__ vlist, const int *__restrict__ finfo,
+    float *__restrict__ out_depth, float *__restrict__ out_dt, int32_t *__restrict__ out_index,
+    int *__restrict__ frame_status, int stop_after) {
+    // ---- P3: tile pixels: walk to the source, d, rank -> label, gather, store.  Each lane walks F_EB
+    // pixels in lock-step (their LDS reads are independent, so the hop latencies overlap) and then has
+    // F_EB global gathers in flight together.
+    const size_t fo = (size_t)b * H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NWAVE = NT / 64;
+    const int nval = finfo[b * FI_STRIDE + FI_NVAL];
+    const int misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
+    bool overflow = false;
+    for (int tc = lane; tc < tw; tc += 64) {
+        const int cc = FR + tc;
+        for (int trb = wave; trb < th; trb += NWAVE * F_EB) {
+            int pos[F_EB], code[F_EB];  // pos = row * F_P + col: byte index of the walker in s_par
+            bool ok[F_EB];
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) {
+                const int tr = trb + e * NWAVE;
+                pos[e] = (FR + min(tr, th - 1)) * F_P + cc;
+                code[e] = s_par[pos[e]];
+                ok[e] = tr < th && code[e] != F_NONE;
+                overflow |= tr < th && code[e] == F_NONE;  // undecidable here: the frame takes the general path
+            }
+            // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
+            // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
+            // overlap.  Two hops between "everybody arrived?" checks.
+            for (int hop = 0; hop < FR; hop += 2) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                    for (int e = 0; e < F_EB; ++e) {
+                        const int c = code[e];
+                        pos[e] += (int)((c >> 3) & 7) * F_P + (c & 7) - (2 * F_P + 2);
+                    }
+#pragma unroll
+                    for (int e = 0; e < F_EB; ++e) code[e] = s_par[pos[e]];
+                }
+                int notdone = 0;
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) notdone |= (code[e] | 0x40) ^ F_NONE;  // 0 iff step (0,0)
+                if (!__any(notdone != 0)) break;
+            }
+            if (stop_after == 3) {  // timing only: keep the walk alive, skip the rest
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(pos[e]));
+                continue;
+            }
+            int lab[F_EB], goff[F_EB], dd[F_EB];
+            float val[F_EB];
+            bool bad = false;
+            const float *gbase = misaligned ? vlist + fo : x + fo;  // block-uniform
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) {
+                // a decided chain ends on a source inside the in-image window; the clamps only make sure
+                // that a logic error could never become a wild global access
+                const int pr_ = pos[e] / F_P, pc_ = pos[e] - pr_ * F_P;
+                const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
+                const int tr = min(trb + e * NWAVE, th - 1);
+                dd[e] = abs(r_ - (FR + tr)) + abs(c_ - cc);  // L1 distance to the nearest source IS d
+                const int gj = wc0 + c_;
+                const int k = r_ * 4 + (gj >> 6) - w0;
+                const u32 lo = s_sb[2 * k], hi = s_sb[2 * k + 1];
+                const u32 below = (1u << (gj & 31)) - 1u;
+                lab[e] = (int)s_rk[k] + ((gj & 32) ? __popc(lo) + __popc(hi & below) : __popc(lo & below)) + 1;
+                // depth_list[label-1] (tools.py:26).  A decided pixel has label >= 1, so the numpy wrap of
+                // index -1 cannot occur here; an index past the value list is numpy's IndexError.
+                const int idx = lab[e] - 1;
+                const bool oob = idx >= nval;
+                bad |= ok[e] && oob;
+                goff[e] = oob ? 0 : (misaligned ? idx : (wr0 + r_) * W + gj);  // masks agree: the label-th value is x at the source
+            }
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) val[e] = gbase[goff[e]];
+            if (stop_after == 4) {
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(val[e]), "v"(lab[e]), "v"(dd[e]));
+                continue;
+            }
+            if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) {
+                if (!ok[e]) continue;
+                const size_t o = fo + (size_t)(r0 + trb + e * NWAVE) * W + (c0 + tc);
+                if (out_index) out_index[o] = lab[e];
+                if (out_dt) out_dt[o] = (float)dd[e];
+                if (out_depth) out_depth[o] = val[e];
+            }
+        }
+    }
+    return overflow;
+}
+
 // FR = halo = largest distance the window can decide.  gate (nullable): only frames with gate[b] != 0
 // are processed (the second, FR = 32 stage only redoes the frames the FR = 16 stage flagged).
 template <int FR>
@@ -98,8 +199,7 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     __shared__ u32 s_sb[F_WHM * 8];  // source bits of the window rows, image-aligned 64-pixel words (as u32 pairs)
     __shared__ u32 s_rk[F_WHM * 4];  // sources before each of those 64-pixel words (frame raster order)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NWAVE = F_NT / 64;
+    const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * TH, c0 = tx * TW;
@@ -281,92 +381,9 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     __syncthreads();
     if (stop_after == 2) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
-    // ---- P3: tile pixels: walk to the source, d, rank -> label, gather, store.  Each lane walks F_EB
-    // pixels in lock-step (their LDS reads are independent, so the hop latencies overlap) and then has
-    // F_EB global gathers in flight together.
-    const size_t fo = (size_t)b * H * W;
-    const int nval = finfo[b * FI_STRIDE + FI_NVAL];
-    const int misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
-    bool overflow = false;
-    for (int tc = lane; tc < tw; tc += 64) {
-        const int cc = FR + tc;
-        for (int trb = wave; trb < th; trb += NWAVE * F_EB) {
-            int pos[F_EB], code[F_EB];  // pos = row * F_P + col: byte index of the walker in s_par
-            bool ok[F_EB];
-#pragma unroll
-            for (int e = 0; e < F_EB; ++e) {
-                const int tr = trb + e * NWAVE;
-                pos[e] = (FR + min(tr, th - 1)) * F_P + cc;
-                code[e] = s_par[pos[e]];
-                ok[e] = tr < th && code[e] != F_NONE;
-                overflow |= tr < th && code[e] == F_NONE;  // undecidable here: the frame takes the general path
-            }
-            // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
-            // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
-            // overlap.  Two hops between "everybody arrived?" checks.
-            for (int hop = 0; hop < FR; hop += 2) {
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-                    for (int e = 0; e < F_EB; ++e) {
-                        const int c = code[e];
-                        pos[e] += (int)((c >> 3) & 7) * F_P + (c & 7) - (2 * F_P + 2);
-                    }
-#pragma unroll
-                    for (int e = 0; e < F_EB; ++e) code[e] = s_par[pos[e]];
-                }
-                int notdone = 0;
-#pragma unroll
-                for (int e = 0; e < F_EB; ++e) notdone |= (code[e] | 0x40) ^ F_NONE;  // 0 iff step (0,0)
-                if (!__any(notdone != 0)) break;
-            }
-            if (stop_after == 3) {  // timing only: keep the walk alive, skip the rest
-#pragma unroll
-                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(pos[e]));
-                continue;
-            }
-            int lab[F_EB], goff[F_EB], dd[F_EB];
-            float val[F_EB];
-            bool bad = false;
-            const float *gbase = misaligned ? vlist + fo : x + fo;  // block-uniform
-#pragma unroll
-            for (int e = 0; e < F_EB; ++e) {
-                // a decided chain ends on a source inside the in-image window; the clamps only make sure
-                // that a logic error could never become a wild global access
-                const int pr_ = pos[e] / F_P, pc_ = pos[e] - pr_ * F_P;
-                const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
-                const int tr = min(trb + e * NWAVE, th - 1);
-                dd[e] = abs(r_ - (FR + tr)) + abs(c_ - cc);  // L1 distance to the nearest source IS d
-                const int gj = wc0 + c_;
-                const int k = r_ * 4 + (gj >> 6) - w0;
-                const u32 lo = s_sb[2 * k], hi = s_sb[2 * k + 1];
-                const u32 below = (1u << (gj & 31)) - 1u;
-                lab[e] = (int)s_rk[k] + ((gj & 32) ? __popc(lo) + __popc(hi & below) : __popc(lo & below)) + 1;
-                // depth_list[label-1] (tools.py:26).  A decided pixel has label >= 1, so the numpy wrap of
-                // index -1 cannot occur here; an index past the value list is numpy's IndexError.
-                const int idx = lab[e] - 1;
-                const bool oob = idx >= nval;
-                bad |= ok[e] && oob;
-                goff[e] = oob ? 0 : (misaligned ? idx : (wr0 + r_) * W + gj);  // masks agree: the label-th value is x at the source
-            }
-#pragma unroll
-            for (int e = 0; e < F_EB; ++e) val[e] = gbase[goff[e]];
-            if (stop_after == 4) {
-#pragma unroll
-                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(val[e]), "v"(lab[e]), "v"(dd[e]));
-                continue;
-            }
-            if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
-#pragma unroll
-            for (int e = 0; e < F_EB; ++e) {
-                if (!ok[e]) continue;
-                const size_t o = fo + (size_t)(r0 + trb + e * NWAVE) * W + (c0 + tc);
-                if (out_index) out_index[o] = lab[e];
-                if (out_dt) out_dt[o] = (float)dd[e];
-                if (out_depth) out_depth[o] = val[e];
-            }
-        }
-    }
+    const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_sb, s_rk, b, H, W, th, tw, r0, c0, wr0, wc0, ra, rb, ca, cb,
+                                                        w0, x, vlist, finfo, out_depth, out_dt, out_index, frame_status,
+                                                        stop_after);
     if (overflow) {
         fflag[b] = 1;  // same-value race
         if (FR == 32) atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);  // last fused stage: general path next
