@@ -90,23 +90,31 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     // pixels in lock-step (their LDS reads are independent, so the hop latencies overlap) and then has
     // F_EB global gathers in flight together.
     const size_t fo = (size_t)b * H * W;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NWAVE = NT / 64;
     const int nval = finfo[b * FI_STRIDE + FI_NVAL];
     const int misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
     bool overflow = false;
-    for (int tc = lane; tc < tw; tc += 64) {
-        const int cc = FR + tc;
-        for (int trb = wave; trb < th; trb += NWAVE * F_EB) {
-            int pos[F_EB], code[F_EB];  // pos = row * F_P + col: byte index of the walker in s_par
+    // Tile pixels in raster order over the threads: pixel p = pb + e * NT + tid, so every batch but the last
+    // has all lanes busy whatever th x tw is, and a wave's stores are runs of consecutive pixels.
+    const int npx = th * tw;
+    const float inv_tw = 1.0f / (float)tw;
+    for (int pb = 0; pb < npx; pb += NT * F_EB) {
+        {
+            int pos[F_EB], code[F_EB], home[F_EB], opix[F_EB];  // pos = row * F_P + col: byte index in s_par
             bool ok[F_EB];
 #pragma unroll
             for (int e = 0; e < F_EB; ++e) {
-                const int tr = trb + e * NWAVE;
-                pos[e] = (FR + min(tr, th - 1)) * F_P + cc;
+                const int p = pb + e * NT + (int)threadIdx.x;
+                const int pc = min(p, npx - 1);
+                // p / tw: (p + 0.5) / tw is at least 0.5 / tw away from an integer, far above float rounding
+                // for p < 2^14, tw < 2^8
+                const int tr = (int)(((float)pc + 0.5f) * inv_tw);
+                const int tc = pc - tr * tw;
+                home[e] = (FR + tr) * F_P + FR + tc;
+                opix[e] = (r0 + tr) * W + c0 + tc;
+                pos[e] = home[e];
                 code[e] = s_par[pos[e]];
-                ok[e] = tr < th && code[e] != F_NONE;
-                overflow |= tr < th && code[e] == F_NONE;  // undecidable here: the frame takes the general path
+                ok[e] = p < npx && code[e] != F_NONE;
+                overflow |= p < npx && code[e] == F_NONE;  // undecidable here: the frame takes the general path
             }
             // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
             // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
@@ -142,8 +150,8 @@ __device__ __forceinline__ bool fused_walk_epilogue(
                 // that a logic error could never become a wild global access
                 const int pr_ = pos[e] / F_P, pc_ = pos[e] - pr_ * F_P;
                 const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
-                const int tr = min(trb + e * NWAVE, th - 1);
-                dd[e] = abs(r_ - (FR + tr)) + abs(c_ - cc);  // L1 distance to the nearest source IS d
+                const int hr = home[e] / F_P, hc = home[e] - hr * F_P;
+                dd[e] = abs(r_ - hr) + abs(c_ - hc);  // L1 distance to the nearest source IS d
                 const int gj = wc0 + c_;
                 const int k = r_ * 4 + (gj >> 6) - w0;
                 const u32 lo = s_sb[2 * k], hi = s_sb[2 * k + 1];
@@ -167,7 +175,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
 #pragma unroll
             for (int e = 0; e < F_EB; ++e) {
                 if (!ok[e]) continue;
-                const size_t o = fo + (size_t)(r0 + trb + e * NWAVE) * W + (c0 + tc);
+                const size_t o = fo + (size_t)opix[e];
                 if (out_index) out_index[o] = lab[e];
                 if (out_dt) out_dt[o] = (float)dd[e];
                 if (out_depth) out_depth[o] = val[e];
