@@ -81,7 +81,7 @@ __device__ __forceinline__ void ring_store3(u32 *__restrict__ ring, int slot, in
 // was undecided.  NT = threads of the calling block.
 template <int FR, int NT>
 __device__ __forceinline__ bool fused_walk_epilogue(
-    const u8 *__restrict__ s_par, const u32 *__restrict__ s_sb, const u32 *__restrict__ s_rk, int b, int H, int W,
+    const u8 *__restrict__ s_par, const u64 *__restrict__ s_sb, const u32 *__restrict__ s_rk, int b, int H, int W,
     int th, int tw, int r0, int c0, int wr0, int wc0, int ra, int rb, int ca, int cb, int w0,
     const float *__restrict__ x, const float *__restrict__ vlist, const int *__restrict__ finfo,
     float *__restrict__ out_depth, float *__restrict__ out_dt, int32_t *__restrict__ out_index,
@@ -95,93 +95,94 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     bool overflow = false;
     // Tile pixels in raster order over the threads: pixel p = pb + e * NT + tid, so every batch but the last
     // has all lanes busy whatever th x tw is, and a wave's stores are runs of consecutive pixels.
+    // Software pipeline: the gathers of one batch stay in flight during the walk of the next batch (LDS only);
+    // a batch's stores are issued just before the next batch's gathers.
     const int npx = th * tw;
     const float inv_tw = 1.0f / (float)tw;
-    for (int pb = 0; pb < npx; pb += NT * F_EB) {
-        {
-            int pos[F_EB], code[F_EB], home[F_EB], opix[F_EB];  // pos = row * F_P + col: byte index in s_par
-            bool ok[F_EB];
+    const float *gbase = misaligned ? vlist + fo : x + fo;  // block-uniform
+    int p_lab[F_EB], p_dd[F_EB], p_opix[F_EB];  // the batch whose gathers are in flight
+    float p_val[F_EB];
+    u32 p_ok = 0;
+    auto retire = [&]() {
 #pragma unroll
-            for (int e = 0; e < F_EB; ++e) {
-                const int p = pb + e * NT + (int)threadIdx.x;
-                const int pc = min(p, npx - 1);
-                // p / tw: (p + 0.5) / tw is at least 0.5 / tw away from an integer, far above float rounding
-                // for p < 2^14, tw < 2^8
-                const int tr = (int)(((float)pc + 0.5f) * inv_tw);
-                const int tc = pc - tr * tw;
-                home[e] = (FR + tr) * F_P + FR + tc;
-                opix[e] = (r0 + tr) * W + c0 + tc;
-                pos[e] = home[e];
-                code[e] = s_par[pos[e]];
-                ok[e] = p < npx && code[e] != F_NONE;
-                overflow |= p < npx && code[e] == F_NONE;  // undecidable here: the frame takes the general path
-            }
-            // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
-            // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
-            // overlap.  Two hops between "everybody arrived?" checks.
-            for (int hop = 0; hop < FR; hop += 2) {
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-                    for (int e = 0; e < F_EB; ++e) {
-                        const int c = code[e];
-                        pos[e] += (int)((c >> 3) & 7) * F_P + (c & 7) - (2 * F_P + 2);
-                    }
-#pragma unroll
-                    for (int e = 0; e < F_EB; ++e) code[e] = s_par[pos[e]];
-                }
-                int notdone = 0;
-#pragma unroll
-                for (int e = 0; e < F_EB; ++e) notdone |= (code[e] | 0x40) ^ F_NONE;  // 0 iff step (0,0)
-                if (!__any(notdone != 0)) break;
-            }
-            if (stop_after == 3) {  // timing only: keep the walk alive, skip the rest
-#pragma unroll
-                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(pos[e]));
-                continue;
-            }
-            int lab[F_EB], goff[F_EB], dd[F_EB];
-            float val[F_EB];
-            bool bad = false;
-            const float *gbase = misaligned ? vlist + fo : x + fo;  // block-uniform
-#pragma unroll
-            for (int e = 0; e < F_EB; ++e) {
-                // a decided chain ends on a source inside the in-image window; the clamps only make sure
-                // that a logic error could never become a wild global access
-                const int pr_ = pos[e] / F_P, pc_ = pos[e] - pr_ * F_P;
-                const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
-                const int hr = home[e] / F_P, hc = home[e] - hr * F_P;
-                dd[e] = abs(r_ - hr) + abs(c_ - hc);  // L1 distance to the nearest source IS d
-                const int gj = wc0 + c_;
-                const int k = r_ * 4 + (gj >> 6) - w0;
-                const u32 lo = s_sb[2 * k], hi = s_sb[2 * k + 1];
-                const u32 below = (1u << (gj & 31)) - 1u;
-                lab[e] = (int)s_rk[k] + ((gj & 32) ? __popc(lo) + __popc(hi & below) : __popc(lo & below)) + 1;
-                // depth_list[label-1] (tools.py:26).  A decided pixel has label >= 1, so the numpy wrap of
-                // index -1 cannot occur here; an index past the value list is numpy's IndexError.
-                const int idx = lab[e] - 1;
-                const bool oob = idx >= nval;
-                bad |= ok[e] && oob;
-                goff[e] = oob ? 0 : (misaligned ? idx : (wr0 + r_) * W + gj);  // masks agree: the label-th value is x at the source
-            }
-#pragma unroll
-            for (int e = 0; e < F_EB; ++e) val[e] = gbase[goff[e]];
-            if (stop_after == 4) {
-#pragma unroll
-                for (int e = 0; e < F_EB; ++e) asm volatile("" ::"v"(val[e]), "v"(lab[e]), "v"(dd[e]));
-                continue;
-            }
-            if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
-#pragma unroll
-            for (int e = 0; e < F_EB; ++e) {
-                if (!ok[e]) continue;
-                const size_t o = fo + (size_t)opix[e];
-                if (out_index) out_index[o] = lab[e];
-                if (out_dt) out_dt[o] = (float)dd[e];
-                if (out_depth) out_depth[o] = val[e];
-            }
+        for (int e = 0; e < F_EB; ++e) {
+            if (!((p_ok >> e) & 1u)) continue;
+            const size_t o = fo + (size_t)p_opix[e];
+            if (out_index) out_index[o] = p_lab[e];
+            if (out_dt) out_dt[o] = (float)p_dd[e];
+            if (out_depth) out_depth[o] = p_val[e];
         }
+    };
+    for (int pb = 0; pb < npx; pb += NT * F_EB) {
+        int pos[F_EB], code[F_EB], home[F_EB], opix[F_EB];  // pos = row * F_P + col: byte index in s_par
+        u32 ok = 0;
+#pragma unroll
+        for (int e = 0; e < F_EB; ++e) {
+            const int p = pb + e * NT + (int)threadIdx.x;
+            const int pc = min(p, npx - 1);
+            // p / tw: (p + 0.5) / tw is at least 0.5 / tw away from an integer, far above float rounding
+            // for p < 2^14, tw < 2^8
+            const int tr = (int)(((float)pc + 0.5f) * inv_tw);
+            const int tc = pc - tr * tw;
+            home[e] = (FR + tr) * F_P + FR + tc;
+            opix[e] = (r0 + tr) * W + c0 + tc;
+            pos[e] = home[e];
+            code[e] = s_par[pos[e]];
+            ok |= (p < npx && code[e] != F_NONE) ? (1u << e) : 0u;
+            overflow |= p < npx && code[e] == F_NONE;  // undecidable here: the frame takes the general path
+        }
+        // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
+        // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
+        // overlap.  Two hops between "everybody arrived?" checks.
+        for (int hop = 0; hop < FR; hop += 2) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) {
+                    const int c = code[e];
+                    pos[e] += (int)((c >> 3) & 7) * F_P + (c & 7) - (2 * F_P + 2);
+                }
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) code[e] = s_par[pos[e]];
+            }
+            int notdone = 0;
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) notdone |= (code[e] | 0x40) ^ F_NONE;  // 0 iff step (0,0)
+            if (!__any(notdone != 0)) break;
+        }
+        int lab[F_EB], goff[F_EB], dd[F_EB];
+        bool bad = false;
+#pragma unroll
+        for (int e = 0; e < F_EB; ++e) {
+            // a decided chain ends on a source inside the in-image window; the clamps only make sure
+            // that a logic error could never become a wild global access
+            const int pr_ = pos[e] / F_P, pc_ = pos[e] - pr_ * F_P;
+            const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
+            const int hr = home[e] / F_P, hc = home[e] - hr * F_P;
+            dd[e] = abs(r_ - hr) + abs(c_ - hc);  // L1 distance to the nearest source IS d
+            const int gj = wc0 + c_;
+            const int k = r_ * 4 + (gj >> 6) - w0;
+            const u64 below = (1ull << (gj & 63)) - 1ull;  // straight-line: one 64-bit LDS read, no select
+            lab[e] = (int)s_rk[k] + __popcll(s_sb[k] & below) + 1;
+            // depth_list[label-1] (tools.py:26).  A decided pixel has label >= 1, so the numpy wrap of
+            // index -1 cannot occur here; an index past the value list is numpy's IndexError.
+            const int idx = lab[e] - 1;
+            const bool oob = idx >= nval;
+            bad |= ((ok >> e) & 1u) && oob;
+            goff[e] = oob ? 0 : (misaligned ? idx : (wr0 + r_) * W + gj);  // masks agree: the label-th value is x at the source
+        }
+        if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
+        retire();  // the previous batch: its gathers had the whole walk above to arrive
+#pragma unroll
+        for (int e = 0; e < F_EB; ++e) {
+            p_val[e] = gbase[goff[e]];
+            p_lab[e] = lab[e];
+            p_dd[e] = dd[e];
+            p_opix[e] = opix[e];
+        }
+        p_ok = ok;
     }
+    retire();
     return overflow;
 }
 
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     const long long h_nsrc = finfo[blockIdx.y * FI_STRIDE + FI_NSRC];
     const int h_dlb = finfo[blockIdx.y * FI_STRIDE + FI_DLB];
     __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
-    __shared__ u32 s_sb[F_WHM * 8];  // source bits of the window rows, image-aligned 64-pixel words (as u32 pairs)
+    __shared__ u64 s_sb[F_WHM * 4];  // source bits of the window rows, image-aligned 64-pixel words
     __shared__ u32 s_rk[F_WHM * 4];  // sources before each of those 64-pixel words (frame raster order)
 
     const int tid = threadIdx.x;
@@ -249,8 +250,7 @@ __global__ __launch_bounds__(F_NT) void k_fused(
             // if half 1 starts later), half 1 the rest
             const bool mine = hf == 0 ? kk < 2 : (kk >= 2 && kk < 4);
             if (mine) {
-                s_sb[r * 8 + 2 * kk] = g[2 * k];
-                s_sb[r * 8 + 2 * kk + 1] = g[2 * k + 1];
+                s_sb[r * 4 + kk] = sb;
                 s_rk[r * 4 + kk] = rk;
             }
         }
