@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import METRICS, DtfillError, build, load
 from .sharding import shard_range, gather_frames, fill_sharded
 from .tools import DT_complete_batch, Distance_Transform, generate_multi_channel, nearest_point, outlier_removal
+from .postfill import Result, Result_NYU, depth_floor, depth_to_png16, kitti_rows, nyu_eval_crop
 
 
 def __getattr__(name):
@@ -27,4 +28,5 @@ def __getattr__(name):
 __all__ = [
     "nearest_point", "DT_complete_batch", "Distance_Transform", "outlier_removal", "generate_multi_channel", "fill", "DtFill",
     "shard_range", "gather_frames", "fill_sharded", "build", "load", "METRICS", "DtfillError",
+    "Result", "Result_NYU", "depth_floor", "depth_to_png16", "kitti_rows", "nyu_eval_crop",
 ]

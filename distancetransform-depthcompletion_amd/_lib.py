@@ -34,7 +34,14 @@ SYMBOLS = (
     "dtfill_batch_timed",
     "dtfill_outlier_removal",
     "dtfill_generate_multi_channel",
+    "dtfill_crop_floor",
+    "dtfill_png16",
+    "dtfill_metrics_workspace_bytes",
+    "dtfill_metrics",
 )
+METRICS_KITTI = 0
+METRICS_NYU = 1
+METRICS_COLUMNS = ("mse", "rmse", "mae", "irmse", "imae", "delta1", "delta2", "delta3", "count")
 
 _lib = None
 
@@ -89,6 +96,14 @@ def load():
     L.dtfill_outlier_removal.restype = ci
     L.dtfill_generate_multi_channel.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
     L.dtfill_generate_multi_channel.restype = ci
+    L.dtfill_crop_floor.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp]
+    L.dtfill_crop_floor.restype = ci
+    L.dtfill_png16.argtypes = [vp, ci, ci, ci, ci, ci, cf, cf, cf, cf, vp, vp]
+    L.dtfill_png16.restype = ci
+    L.dtfill_metrics_workspace_bytes.argtypes = [ci]
+    L.dtfill_metrics_workspace_bytes.restype = sz
+    L.dtfill_metrics.argtypes = [vp, vp, ci, ctypes.c_longlong, ci, vp, vp, sz, vp]
+    L.dtfill_metrics.restype = ci
     _lib = L
     return L
 

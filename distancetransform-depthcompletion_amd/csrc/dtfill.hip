@@ -67,6 +67,7 @@ namespace {
 #include "dtfill_l2.hpp"
 #include "dtfill_outlier.hpp"
 #include "dtfill_gmc.hpp"
+#include "dtfill_post.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -346,6 +347,51 @@ int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float
     for (int k = 0; k < nk; ++k) (void)hipEventElapsedTime(&kernel_ms[k], ev[k], ev[k + 1]);
     for (int k = 0; k <= nk; ++k) (void)hipEventDestroy(ev[k]);
     return rc;
+}
+
+int dtfill_crop_floor(const float *x, int B, int H, int W, int r0, int r1, int c0, int c1, int use_floor, float floor_,
+                      float *out, void *stream) {
+    if (!x || !out) return DTFILL_ERR_NULL;
+    if (B < 1 || H < 1 || W < 1 || (long long)B * H * W >= (1ll << 31) || B > 65535 || H > 65535) return DTFILL_ERR_SHAPE;
+    if (r0 < 0 || r1 > H || r0 >= r1 || c0 < 0 || c1 > W || c0 >= c1) return DTFILL_ERR_SHAPE;
+    const int OH = r1 - r0, OW = c1 - c0;
+    k_crop_floor<<<dim3(min((OW + 255) / 256, 8), OH, B), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        x, H, W, r0, c0, OH, OW, use_floor, floor_, out);
+    return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
+}
+
+int dtfill_png16(const float *x, int B, int H, int W, int pad_top, int use_floor, float floor_, float lo, float hi,
+                 float scale, uint16_t *out, void *stream) {
+    if (!x || !out) return DTFILL_ERR_NULL;
+    if (B < 1 || H < 1 || W < 1 || pad_top < 0 || (long long)B * ((long long)H + pad_top) * W >= (1ll << 31) || B > 65535 ||
+        H + pad_top > 65535)
+        return DTFILL_ERR_SHAPE;
+    k_png16<<<dim3(min((W + 255) / 256, 8), H + pad_top, B), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        x, H, W, pad_top, use_floor, floor_, lo, hi, scale, out);
+    return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
+}
+
+size_t dtfill_metrics_workspace_bytes(int B) {
+    if (B < 1 || B > 65535) return 0;
+    return (size_t)B * M_NB * M_NS * sizeof(double);
+}
+
+int dtfill_metrics(const float *output, const float *target, int B, long long n, int kind, double *out, void *workspace,
+                   size_t ws_bytes, void *stream) {
+    if (!output || !target || !out || !workspace) return DTFILL_ERR_NULL;
+    if (B < 1 || B > 65535 || n < 1 || n >= (1ll << 40)) return DTFILL_ERR_SHAPE;
+    if (kind != DTFILL_METRICS_KITTI && kind != DTFILL_METRICS_NYU) return DTFILL_ERR_METRIC;
+    if (ws_bytes < dtfill_metrics_workspace_bytes(B)) return DTFILL_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double *part = static_cast<double *>(workspace);
+    if (kind == DTFILL_METRICS_KITTI) {
+        k_metrics_part<0><<<dim3(M_NB, B), 256, 0, st>>>(output, target, n, part);
+        k_metrics_final<0><<<B, 64, 0, st>>>(part, M_NB, out);
+    } else {
+        k_metrics_part<1><<<dim3(M_NB, B), 256, 0, st>>>(output, target, n, part);
+        k_metrics_final<1><<<B, 64, 0, st>>>(part, M_NB, out);
+    }
+    return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
 
 }  // extern "C"

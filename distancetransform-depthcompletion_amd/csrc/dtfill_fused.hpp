@@ -85,7 +85,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     int th, int tw, int r0, int c0, int wr0, int wc0, int ra, int rb, int ca, int cb, int w0,
     const float *__restrict__ x, const float *__restrict__ vlist, const int *__restrict__ finfo,
     float *__restrict__ out_depth, float *__restrict__ out_dt, int32_t *__restrict__ out_index,
-    int *__restrict__ frame_status, int stop_after) {
+    int *__restrict__ frame_status) {
     // ---- P3: tile pixels: walk to the source, d, rank -> label, gather, store.  Each lane walks F_EB
     // pixels in lock-step (their LDS reads are independent, so the hop latencies overlap) and then has
     // F_EB global gathers in flight together.
@@ -390,8 +390,7 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     if (stop_after == 2) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
     const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_sb, s_rk, b, H, W, th, tw, r0, c0, wr0, wc0, ra, rb, ca, cb,
-                                                        w0, x, vlist, finfo, out_depth, out_dt, out_index, frame_status,
-                                                        stop_after);
+                                                        w0, x, vlist, finfo, out_depth, out_dt, out_index, frame_status);
     if (overflow) {
         fflag[b] = 1;  // same-value race
         if (FR == 32) atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);  // last fused stage: general path next

@@ -167,6 +167,66 @@ def generate_multi_channel_device(data, mask, table_size=7, scale_num=4):
     return tuple([data] + outs + [None] * (4 - scale_num))
 
 
+def _check_frames(t, what):
+    if t.dtype != torch.float32 or not t.is_cuda or t.dim() != 3 or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous float32 CUDA tensor [B,H,W]" % what)
+
+
+def crop_floor_device(x, rows=None, cols=None, floor=None):
+    """out = f(x[:, rows[0]:rows[1], cols[0]:cols[1]]); f = relu(d - floor) + floor when floor is given
+    (demo.py:292-293, eval_NYU.py:202-205).  x: contiguous float32 CUDA tensor [B,H,W] -> new tensor."""
+    _require_gpu()
+    _check_frames(x, "x")
+    B, H, W = x.shape
+    r0, r1 = (0, H) if rows is None else rows
+    c0, c1 = (0, W) if cols is None else cols
+    if not (0 <= r0 < r1 <= H and 0 <= c0 < c1 <= W):
+        raise ValueError("empty or out-of-frame crop rows=%s cols=%s of a %dx%d frame" % (rows, cols, H, W))
+    out = torch.empty((B, r1 - r0, c1 - c0), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dtfill_crop_floor(x.data_ptr(), B, H, W, r0, r1, c0, c1, int(floor is not None),
+                                                 float(floor or 0.0), out.data_ptr(),
+                                                 torch.cuda.current_stream(x.device).cuda_stream))
+    return out
+
+
+def png16_device(x, pad_top=96, floor=0.9, lo=0.0, hi=100.0, scale=256.0):
+    """test.py:133-148 on the device: x float32 CUDA [B,H,W] -> uint16 CUDA [B, pad_top+H, W]."""
+    _require_gpu()
+    _check_frames(x, "x")
+    B, H, W = x.shape
+    out = torch.empty((B, H + pad_top, W), dtype=torch.uint16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().dtfill_png16(x.data_ptr(), B, H, W, pad_top, int(floor is not None), float(floor or 0.0),
+                                            lo, hi, scale, out.data_ptr(),
+                                            torch.cuda.current_stream(x.device).cuda_stream))
+    return out
+
+
+def metrics_device(output, target, kind="kitti"):
+    """evaluation.py:82-123 (kind "kitti") / :196-239 ("nyu"), one row per frame.  output, target: contiguous
+    float32 CUDA tensors [B, ...] of equal shape -> float64 CUDA tensor [B, 9], columns _lib.METRICS_COLUMNS."""
+    _require_gpu()
+    kinds = {"kitti": _lib.METRICS_KITTI, "nyu": _lib.METRICS_NYU}
+    if kind not in kinds:
+        raise ValueError("kind must be 'kitti' or 'nyu'")
+    for t in (output, target):
+        if t.dtype != torch.float32 or not t.is_cuda or t.dim() < 2 or not t.is_contiguous():
+            raise ValueError("output and target must be contiguous float32 CUDA tensors [B, ...]")
+    if output.shape != target.shape:
+        raise ValueError("output and target shapes differ")
+    B = output.shape[0]
+    n = output[0].numel()
+    L = _lib.load()
+    nbytes = L.dtfill_metrics_workspace_bytes(B)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=output.device)
+    out = torch.empty((B, len(_lib.METRICS_COLUMNS)), dtype=torch.float64, device=output.device)
+    with torch.cuda.device(output.device):
+        _lib.check(L.dtfill_metrics(output.data_ptr(), target.data_ptr(), B, n, kinds[kind], out.data_ptr(),
+                                    ws.data_ptr(), nbytes, torch.cuda.current_stream(output.device).cuda_stream))
+    return out
+
+
 _default_ops = {}
 
 

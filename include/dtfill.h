@@ -128,6 +128,43 @@ int dtfill_outlier_removal(const float *x, int B, int H, int W, float *out, void
 int dtfill_generate_multi_channel(const float *data, const float *mask, int B, int H, int W, int table_size,
                                   int scale_num, float *out2, float *out3, float *out4, void *stream);
 
+/*
+ * What the reference's drivers do with a filled frame.
+ *
+ * dtfill_crop_floor: out[b, i, j] = f(x[b, r0+i, c0+j]) for rows [r0, r1), columns [c0, c1); f is the depth
+ * floor relu(d - floor) + floor in float32, both roundings kept (eval_NYU.py:205, test.py:133: floor 0.9), when
+ * use_floor != 0, the identity otherwise.  Replaces lidar_batch[:, 96:, :, :] (demo.py:292-293), the NYU
+ * evaluation crop [6:234, 8:312] (eval_NYU.py:202-203) and the KITTI depth floor (eval_NYU.py:205).
+ * x: float32 [B,H,W]; out: float32 [B, r1-r0, c1-c0], may not alias x.
+ *
+ * dtfill_png16: test.py:133-148 -- depth floor (if use_floor), clip to [lo, hi] (0, 100), pad_top (96) copies
+ * of the first row on top, * scale (256), cast to uint16.  out: uint16 [B, pad_top+H, W].
+ */
+int dtfill_crop_floor(const float *x, int B, int H, int W, int r0, int r1, int c0, int c1, int use_floor, float floor_,
+                      float *out, void *stream);
+int dtfill_png16(const float *x, int B, int H, int W, int pad_top, int use_floor, float floor_, float lo, float hi,
+                 float scale, uint16_t *out, void *stream);
+
+/*
+ * Error metrics of evaluation.py, one row per frame:
+ *   DTFILL_METRICS_KITTI  Result.evaluate, evaluation.py:82-123 (metres -> mm for mse/rmse/mae, -> 1/km for
+ *                         irmse/imae; the deltas stay 0 as in the reference);
+ *   DTFILL_METRICS_NYU    Result_NYU.evaluate, evaluation.py:196-239 (no unit change, mae = mean(|d|/target),
+ *                         delta1..3 = mean(max(o/t, t/o) < 1.25^k)).
+ * Elements with output > 0.01 and target > 0.01 count.  Per element the float32 arithmetic of the numpy
+ * expressions; the means accumulate in float64 in a fixed order (numpy: float32 pairwise sums), so a result is
+ * reproducible and within ~1e-6 relative of numpy's.  No valid element: NaN (numpy's mean of nothing).
+ * output, target: float32 [B, n] device pointers; out: float64 [B, DTFILL_METRICS_N] device pointer, columns
+ * mse, rmse, mae, irmse, imae, delta1, delta2, delta3, count.  workspace: device scratch of at least
+ * dtfill_metrics_workspace_bytes(B) bytes.
+ */
+#define DTFILL_METRICS_KITTI 0
+#define DTFILL_METRICS_NYU 1
+#define DTFILL_METRICS_N 9
+size_t dtfill_metrics_workspace_bytes(int B);
+int dtfill_metrics(const float *output, const float *target, int B, long long n, int kind, double *out, void *workspace,
+                   size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

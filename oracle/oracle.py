@@ -9,6 +9,10 @@ negative-index / IndexError behaviour of the reference):
   nearest_point       solution_DeepNet/tools.py:7-10, eval_NYU.py:114-117
   DT_complete_batch   solution_DeepNet/tools.py:13-35 (demo.py:84-106)
   Distance_Transform  solution_DeepNet/eval_NYU.py:120-133
+  evaluate_kitti / evaluate_nyu   evaluation.py:82-123 / :196-239 (Result.evaluate, Result_NYU.evaluate)
+  depth_floor, kitti_rows, nyu_eval_crop, depth_to_png16   the drivers' inline post-fill steps
+                      (demo.py:292-293, eval_NYU.py:202-205, test.py:133-148); tf.nn.relu / tf.clip_by_value
+                      restated as np.maximum / np.clip on float32 (tensorflow is absent: unpinned)
 """
 import ctypes
 import os
@@ -209,3 +213,67 @@ def edt_l2(mask):
     near = np.empty((H, W), np.int32)
     lib().edt_l2_labels(_p(mask), H, W, _p(d), _p(near))
     return d, near
+
+
+# ---- post-fill steps of the drivers and the metrics (8f-3) ----------------------------
+
+def depth_floor(d, floor=0.9):
+    """relu(d - 0.9) + 0.9 on float32, one rounding per step (eval_NYU.py:205, test.py:133)."""
+    d = np.asarray(d, np.float32)
+    f = np.float32(floor)
+    return (np.maximum(d - f, np.float32(0.0)) + f).astype(np.float32)
+
+
+def kitti_rows(batch, first_row=96):
+    """lidar_batch[:, 96:, :, :] (demo.py:292-293)."""
+    return np.ascontiguousarray(np.asarray(batch)[:, first_row:])
+
+
+def nyu_eval_crop(frame):
+    """np.squeeze(x)[6:234, 8:312] (eval_NYU.py:202-203)."""
+    return np.ascontiguousarray(np.squeeze(np.asarray(frame))[6:234, 8:312])
+
+
+def depth_to_png16(depth, pad_top=96, floor=0.9, lo=0.0, hi=100.0, scale=256.0):
+    """test.py:133-148: depth floor, clip, pad_top copies of row 0 on top, * 256, astype(uint16)."""
+    d = depth_floor(np.squeeze(np.asarray(depth, np.float32)), floor)
+    d = np.clip(d, np.float32(lo), np.float32(hi))
+    top = np.tile(d[0, :], (pad_top, 1)).astype(np.float32)
+    d = np.vstack((top, d)) if pad_top else d
+    return (d * np.float32(scale)).astype(np.uint16)
+
+
+def _both_valid(output, target):
+    output, target = np.asarray(output), np.asarray(target)
+    keep = np.logical_and(output > 0.01, target > 0.01)  # evaluation.py:85-87 / :199-201
+    return output[keep], target[keep]
+
+
+def evaluate_kitti(output, target):
+    """Result.evaluate (evaluation.py:82-123): mm for mse/rmse/mae, 1/km for irmse/imae."""
+    import math
+    o, t = _both_valid(output, target)
+    with np.errstate(all="ignore"):
+        err = np.abs(1e3 * o - 1e3 * t)
+        mse = np.mean(np.power(err, 2))
+        ierr = np.abs((1e-3 * o) ** (-1) - (1e-3 * t) ** (-1))
+        return {"mse": float(mse), "rmse": math.sqrt(mse) if mse == mse else float("nan"), "mae": float(np.mean(err)),
+                "irmse": float(np.sqrt(np.mean(np.power(ierr, 2)))), "imae": float(np.mean(ierr)),
+                "delta1": 0.0, "delta2": 0.0, "delta3": 0.0, "count": float(o.size)}
+
+
+def evaluate_nyu(output, target):
+    """Result_NYU.evaluate (evaluation.py:196-239): metres, RELATIVE mae, delta accuracies."""
+    import math
+    o, t = _both_valid(output, target)
+    with np.errstate(all="ignore"):
+        err = np.abs(o - t)
+        mse = np.mean(np.power(err, 2))
+        worst = np.maximum(o / t, t / o)
+        ierr = np.abs(o ** (-1) - t ** (-1))
+        imse = np.mean(np.power(ierr, 2))
+        return {"mse": float(mse), "rmse": math.sqrt(mse) if mse == mse else float("nan"),
+                "mae": float(np.mean(err / t)),
+                "irmse": math.sqrt(imse) if imse == imse else float("nan"), "imae": float(np.mean(ierr)),
+                "delta1": float(np.mean(worst < 1.25)), "delta2": float(np.mean(worst < 1.25 ** 2)),
+                "delta3": float(np.mean(worst < 1.25 ** 3)), "count": float(o.size)}
