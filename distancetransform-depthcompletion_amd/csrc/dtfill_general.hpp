@@ -19,7 +19,8 @@ __global__ __launch_bounds__(64 * G_NCH) void k_colscan(const u64 *__restrict__ 
                                                         const int *__restrict__ fflag, int H, int W, int Wd,
                                                         int CR, u16 *__restrict__ gu, u16 *__restrict__ g) {
     __shared__ int s_last[G_NCH][64], s_first[G_NCH][64];
-    const int b = blockIdx.y, wd = blockIdx.x, lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    // ch is wave-uniform: as a scalar, the row loops and row addresses below run on the scalar unit
+    const int b = blockIdx.y, wd = blockIdx.x, lane = threadIdx.x & 63, ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (fflag && !fflag[b]) return;
     const int j = wd * 64 + lane;
     const bool inb = j < W;
@@ -139,7 +140,7 @@ __device__ __forceinline__ int skew_run(const u16 *__restrict__ guf, u16 *__rest
 __global__ __launch_bounds__(64 * G_NCH) void k_skew(const u16 *__restrict__ gu, const int *__restrict__ fflag,
                                                      int H, int W, u16 *__restrict__ dB) {
     __shared__ int s_end[G_NCH][64];
-    const int b = blockIdx.y, lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar
     if (!fflag[b]) return;
     const int nU = W + 2 * (H - 1) + 1;
     const int u0 = blockIdx.x * 64;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, cons
                                                  const u16 *__restrict__ dB, const int *__restrict__ fflag,
                                                  int H, int W, int nseg, u16 *__restrict__ dl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar row index
     const int i = blockIdx.x * (blockDim.x >> 6) + wave, b = blockIdx.y;
     if (!fflag[b] || i >= H) return;  // wave-uniform; no block-level barrier below
     int *s_a = reinterpret_cast<int *>(smem) + (size_t)wave * nseg * 512;  // a | (dA == a) << 24, lane-private slots
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(X_NT) void k_exit(const u16 *__restrict__ dl, const
 
     {   // tile + halo: one wave per row, lanes along the row (coalesced, no divisions); the loads of 8 rows
         // (24 per lane) are issued before the first LDS store, so the memory round trips overlap
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar row index
         for (int rb = wave; rb < X_P; rb += (X_NT / 64) * 8) {
             u16 v[8][3];
 #pragma unroll
