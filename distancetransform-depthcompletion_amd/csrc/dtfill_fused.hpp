@@ -15,10 +15,11 @@
 //   holding the bits of enc = (di+2)<<3 | (dj+2)  (sources: enc 18 = step (0,0)).
 // A horizontal shift of a row is one v_alignbit per word; rows r-2..r+2 of the previous three levels
 // come from a 4-slot LDS ring (one barrier per level).  Levels stop at FR or when a level is empty.
-// Then every lane un-slices its row, 4 pixels per step, into the byte array s_par (0x80 | enc; 0x80
-// itself = undecided), which reuses the ring's memory, and the tile pixels walk to their sources in
-// lock-step; d is |drow| + |dcol| to the root.
-// LDS: 25.3 KB ring/s_par + 6 KB bit words and ranks.
+// Then every lane un-slices its row, 4 pixels per step, into the byte array s_par (2 * enc; F_NONE =
+// undecided), which reuses the ring's memory, and the tile pixels walk to their sources in lock-step:
+// the byte is the byte offset of the step's s_par displacement in a 64-entry int16 table (s_tab), so a
+// hop is two LDS reads and one add; d is |drow| + |dcol| to the root.
+// LDS: 28.9 KB ring/s_par + 6 KB bit words and ranks.
 // ------------------------------------------------------------------------------------------------
 constexpr int F_WHM = 128;  // window rows
 constexpr int F_WWM = 192;  // window columns = 6 words
@@ -32,8 +33,8 @@ constexpr int F_RROWS = F_WHM + 4;     // ring rows: 2 zero rows above and below
 constexpr int F_RPLANE = F_RROWS * F_RS;
 constexpr int F_RING = 1 + 4 * 2 * F_RPLANE;  // one leading zero word, then [slot][plane E/L][row][7]
 constexpr int F_EB = 8;                // tile pixels per lane walked in lock-step
-// byte code of a source: 0x80 | 18 = step (0,0)
-constexpr int F_NONE = 0xC0 | 18;      // byte code of an undecided pixel: also step (0,0), plus bit 6
+// byte code of a decided pixel: 2 * enc (a source: 2 * 18 = step (0,0))
+constexpr int F_NONE = 2 * 63;         // byte code of an undecided pixel: table entry 63, also step (0,0)
 static_assert(F_WWM == 32 * F_NWD, "window width must be six words");
 static_assert(F_RING * 4 >= F_WHM * F_P, "s_par must fit in the ring's memory");
 
@@ -81,17 +82,22 @@ __device__ __forceinline__ void ring_store3(u32 *__restrict__ ring, int slot, in
 // was undecided.  NT = threads of the calling block.
 template <int FR, int NT>
 __device__ __forceinline__ bool fused_walk_epilogue(
-    const u8 *__restrict__ s_par, const u64 *__restrict__ s_sb, const u32 *__restrict__ s_rk, int b, int H, int W,
-    int th, int tw, int r0, int c0, int wr0, int wc0, int ra, int rb, int ca, int cb, int w0,
-    const float *__restrict__ x, const float *__restrict__ vlist, const int *__restrict__ finfo,
-    float *__restrict__ out_depth, float *__restrict__ out_dt, int32_t *__restrict__ out_index,
-    int *__restrict__ frame_status) {
+    const u8 *__restrict__ s_par, const short *__restrict__ s_tab, const u64 *__restrict__ s_sb,
+    const u32 *__restrict__ s_rk, int b, int H, int W, int th, int tw, int r0, int c0, int wr0, int wc0, int ra,
+    int rb, int ca, int cb, int w0, const float *__restrict__ x, const float *__restrict__ vlist,
+    const int *__restrict__ finfo, float *__restrict__ out_depth, float *__restrict__ out_dt,
+    int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
     // ---- P3: tile pixels: walk to the source, d, rank -> label, gather, store.  Each lane walks F_EB
     // pixels in lock-step (their LDS reads are independent, so the hop latencies overlap) and then has
     // F_EB global gathers in flight together.
+    // Frame bases are block-uniform (scalar registers); per pixel only 32-bit in-frame offsets are computed.
     const size_t fo = (size_t)b * H * W;
     const int nval = finfo[b * FI_STRIDE + FI_NVAL];
     const int misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
+    const float *gbase = misaligned ? vlist + fo : x + fo;
+    float *od = out_depth ? out_depth + fo : nullptr, *ot = out_dt ? out_dt + fo : nullptr;
+    int32_t *oi = out_index ? out_index + fo : nullptr;
+    const char *tab = reinterpret_cast<const char *>(s_tab);
     bool overflow = false;
     // Tile pixels in raster order over the threads: pixel p = pb + e * NT + tid, so every batch but the last
     // has all lanes busy whatever th x tw is, and a wave's stores are runs of consecutive pixels.
@@ -99,22 +105,22 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     // a batch's stores are issued just before the next batch's gathers.
     const int npx = th * tw;
     const float inv_tw = 1.0f / (float)tw;
-    const float *gbase = misaligned ? vlist + fo : x + fo;  // block-uniform
-    int p_lab[F_EB], p_dd[F_EB], p_opix[F_EB];  // the batch whose gathers are in flight
+    int p_lab[F_EB], p_dd[F_EB];  // the batch whose gathers are in flight
+    u32 p_opix[F_EB];
     float p_val[F_EB];
     u32 p_ok = 0;
     auto retire = [&]() {
 #pragma unroll
         for (int e = 0; e < F_EB; ++e) {
             if (!((p_ok >> e) & 1u)) continue;
-            const size_t o = fo + (size_t)p_opix[e];
-            if (out_index) out_index[o] = p_lab[e];
-            if (out_dt) out_dt[o] = (float)p_dd[e];
-            if (out_depth) out_depth[o] = p_val[e];
+            if (oi) oi[p_opix[e]] = p_lab[e];
+            if (ot) ot[p_opix[e]] = (float)p_dd[e];
+            if (od) od[p_opix[e]] = p_val[e];
         }
     };
     for (int pb = 0; pb < npx; pb += NT * F_EB) {
-        int pos[F_EB], code[F_EB], home[F_EB], opix[F_EB];  // pos = row * F_P + col: byte index in s_par
+        int pos[F_EB], code[F_EB], hr[F_EB], hc[F_EB];  // pos = row * F_P + col: byte index in s_par
+        u32 opix[F_EB];
         u32 ok = 0;
 #pragma unroll
         for (int e = 0; e < F_EB; ++e) {
@@ -124,9 +130,10 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             // for p < 2^14, tw < 2^8
             const int tr = (int)(((float)pc + 0.5f) * inv_tw);
             const int tc = pc - tr * tw;
-            home[e] = (FR + tr) * F_P + FR + tc;
-            opix[e] = (r0 + tr) * W + c0 + tc;
-            pos[e] = home[e];
+            hr[e] = FR + tr;
+            hc[e] = FR + tc;
+            opix[e] = (u32)((r0 + tr) * W + c0 + tc);
+            pos[e] = hr[e] * F_P + hc[e];
             code[e] = s_par[pos[e]];
             ok |= (p < npx && code[e] != F_NONE) ? (1u << e) : 0u;
             overflow |= p < npx && code[e] == F_NONE;  // undecidable here: the frame takes the general path
@@ -135,20 +142,20 @@ __device__ __forceinline__ bool fused_walk_epilogue(
         // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
         // overlap.  Two hops between "everybody arrived?" checks.
         for (int hop = 0; hop < FR; hop += 2) {
+            int step[F_EB];
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
-                for (int e = 0; e < F_EB; ++e) {
-                    const int c = code[e];
-                    pos[e] += (int)((c >> 3) & 7) * F_P + (c & 7) - (2 * F_P + 2);
-                }
+                for (int e = 0; e < F_EB; ++e) step[e] = *reinterpret_cast<const short *>(tab + code[e]);
+#pragma unroll
+                for (int e = 0; e < F_EB; ++e) pos[e] += step[e];
 #pragma unroll
                 for (int e = 0; e < F_EB; ++e) code[e] = s_par[pos[e]];
             }
-            int notdone = 0;
+            int moved = 0;  // a walker whose last step was (0,0) has arrived
 #pragma unroll
-            for (int e = 0; e < F_EB; ++e) notdone |= (code[e] | 0x40) ^ F_NONE;  // 0 iff step (0,0)
-            if (!__any(notdone != 0)) break;
+            for (int e = 0; e < F_EB; ++e) moved |= step[e];
+            if (!__any(moved != 0)) break;
         }
         int lab[F_EB], goff[F_EB], dd[F_EB];
         bool bad = false;
@@ -158,8 +165,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             // that a logic error could never become a wild global access
             const int pr_ = pos[e] / F_P, pc_ = pos[e] - pr_ * F_P;
             const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
-            const int hr = home[e] / F_P, hc = home[e] - hr * F_P;
-            dd[e] = abs(r_ - hr) + abs(c_ - hc);  // L1 distance to the nearest source IS d
+            dd[e] = abs(r_ - hr[e]) + abs(c_ - hc[e]);  // L1 distance to the nearest source IS d
             const int gj = wc0 + c_;
             const int k = r_ * 4 + (gj >> 6) - w0;
             const u64 below = (1ull << (gj & 63)) - 1ull;  // straight-line: one 64-bit LDS read, no select
@@ -175,7 +181,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
         retire();  // the previous batch: its gathers had the whole walk above to arrive
 #pragma unroll
         for (int e = 0; e < F_EB; ++e) {
-            p_val[e] = gbase[goff[e]];
+            p_val[e] = gbase[(u32)goff[e]];
             p_lab[e] = lab[e];
             p_dd[e] = dd[e];
             p_opix[e] = opix[e];
@@ -207,6 +213,8 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
     __shared__ u64 s_sb[F_WHM * 4];  // source bits of the window rows, image-aligned 64-pixel words
     __shared__ u32 s_rk[F_WHM * 4];  // sources before each of those 64-pixel words (frame raster order)
+    __shared__ short s_tab[64];      // s_par displacement of the step enc (0 for the codes that are no step)
+    __shared__ u32 s_any[2][F_NT / 64];  // per wave: did level t produce anything (double-buffered by level parity)
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -279,6 +287,10 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     }
     // level 0: E_0 = L_0 = sources; zero the rest of the ring (levels "-1,-2,-3", the guard rows, the pads)
     for (int k = tid; k < F_RING; k += F_NT) s_ring[k] = 0;
+    if (tid < 64) {
+        const int hi = tid >> 3, lo = tid & 7;
+        s_tab[tid] = (hi <= 4 && lo <= 4) ? (short)((hi - 2) * F_P + (lo - 2)) : (short)0;
+    }
     __syncthreads();
     ring_store3(s_ring, 0, 0, r + 2, wb, D);
     ring_store3(s_ring, 0, 1, r + 2, wb, D);
@@ -360,7 +372,17 @@ __global__ __launch_bounds__(F_NT) void k_fused(
         for (int i = 0; i < F_HW; ++i) D[i] |= Et[i];
         ring_store3(s_ring, sw, 0, r + 2, wb, Et);
         ring_store3(s_ring, sw, 1, r + 2, wb, Lt);
-        if (!__syncthreads_or(nonempty)) break;  // nothing at distance t anywhere: nothing farther either
+        // "did anybody find a pixel at distance t": one flag per wave, read after the level's only barrier
+        // (__syncthreads_or costs three).  Parity double-buffering: a wave can be at most one level ahead.
+        {
+            const bool wave_any = __any(nonempty);
+            if ((tid & 63) == 0) s_any[t & 1][tid >> 6] = wave_any ? 1u : 0u;
+            __syncthreads();
+            u32 any = 0;
+#pragma unroll
+            for (int w = 0; w < F_NT / 64; ++w) any |= s_any[t & 1][w];
+            if (!any) break;  // nothing at distance t anywhere: nothing farther either
+        }
     }
     if (stop_after == 1) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
@@ -374,22 +396,22 @@ __global__ __launch_bounds__(F_NT) void k_fused(
         for (int i = 0; i < F_HW; ++i) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                u32 v = 0x80808080u;
+                u32 v = 0;
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const u32 nib = (C[j][i] >> (4 * q)) & 0xFu;
-                    v |= ((nib * 0x00204081u) & 0x01010101u) << j;
+                    v |= ((nib * 0x00204081u) & 0x01010101u) << (j + 1);  // byte = 2 * enc
                 }
-                // undecided pixels (not in D): no plane bit is set; give them F_NONE = 0x80 | 0x52
+                // undecided pixels (not in D): no plane bit is set; give them F_NONE
                 const u32 und = ((~D[i] >> (4 * q)) & 0xFu) * 0x00204081u & 0x01010101u;
-                prow[i * 8 + q] = v | und * 0x52u;
+                prow[i * 8 + q] = v | und * (u32)F_NONE;
             }
         }
     }
     __syncthreads();
     if (stop_after == 2) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
-    const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_sb, s_rk, b, H, W, th, tw, r0, c0, wr0, wc0, ra, rb, ca, cb,
+    const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_tab, s_sb, s_rk, b, H, W, th, tw, r0, c0, wr0, wc0, ra, rb, ca, cb,
                                                         w0, x, vlist, finfo, out_depth, out_dt, out_index, frame_status);
     if (overflow) {
         fflag[b] = 1;  // same-value race
