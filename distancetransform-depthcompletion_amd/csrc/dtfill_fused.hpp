@@ -163,9 +163,9 @@ __device__ __forceinline__ bool fused_walk_epilogue(
         for (int e = 0; e < F_EB; ++e) {
             // a decided chain ends on a source inside the in-image window; the clamps only make sure
             // that a logic error could never become a wild global access
-            const int pr_ = pos[e] / F_P, pc_ = pos[e] - pr_ * F_P;
+            const int pr_ = (int)((u32)pos[e] / (u32)F_P), pc_ = pos[e] - pr_ * F_P;
             const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
-            dd[e] = abs(r_ - hr[e]) + abs(c_ - hc[e]);  // L1 distance to the nearest source IS d
+            dd[e] = (int)__sad((u32)r_, (u32)hr[e], __sad((u32)c_, (u32)hc[e], 0u));  // L1 distance to the nearest source IS d
             const int gj = wc0 + c_;
             const int k = r_ * 4 + (gj >> 6) - w0;
             const u64 below = (1ull << (gj & 63)) - 1ull;  // straight-line: one 64-bit LDS read, no select
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     const int r = tid & (F_WHM - 1);  // window row of this lane
     const int hf = tid >> 7;          // which half of the row (wave-uniform)
     const int wb = F_HW * hf;         // first of the lane's three words
-    u32 M[F_HW], D[F_HW];
+    u32 M[F_HW], D[F_HW], TM[F_HW];  // in-image mask, decided pixels, tile pixels (of the lane's three words)
     {
         const int gi = wr0 + r;
         const bool rowin = r < WH && gi >= 0 && gi < H;
@@ -276,6 +276,11 @@ __global__ __launch_bounds__(F_NT) void k_fused(
             if (rowin && up > lo) m = (up >= 32 ? 0xFFFFFFFFu : ((1u << up) - 1u)) & ~((1u << lo) - 1u);
             M[i] = m;
             D[i] = word & m;
+            // tile columns of window word wb + i: [FR, FR + tw) -- rows [FR, FR + th)
+            const int tlo = max(FR - 32 * (wb + i), 0), tup = min(FR + tw - 32 * (wb + i), 32);
+            u32 tm = 0;
+            if (r >= FR && r < FR + th && tup > tlo) tm = (tup >= 32 ? 0xFFFFFFFFu : ((1u << tup) - 1u)) & ~((1u << tlo) - 1u);
+            TM[i] = tm;
         }
     }
     if (h_nsrc * (2 * FR * FR + 2 * FR + 1) < 14ll * H * W || h_dlb > FR) {  // block-uniform
@@ -372,16 +377,22 @@ __global__ __launch_bounds__(F_NT) void k_fused(
         for (int i = 0; i < F_HW; ++i) D[i] |= Et[i];
         ring_store3(s_ring, sw, 0, r + 2, wb, Et);
         ring_store3(s_ring, sw, 1, r + 2, wb, Lt);
-        // "did anybody find a pixel at distance t": one flag per wave, read after the level's only barrier
-        // (__syncthreads_or costs three).  Parity double-buffering: a wave can be at most one level ahead.
+        // Go on while level t produced something (else nothing farther exists either) AND some TILE pixel is
+        // still undecided (a chain only runs through smaller distances, so the halo beyond that is not needed;
+        // halo pixels near the window edge see fewer sources and would drag the loop towards FR).  One flag
+        // word per wave, read after the level's only barrier (__syncthreads_or costs three); double-buffered
+        // by level parity: a wave can be at most one level ahead.
         {
-            const bool wave_any = __any(nonempty);
-            if ((tid & 63) == 0) s_any[t & 1][tid >> 6] = wave_any ? 1u : 0u;
+            bool open = false;
+#pragma unroll
+            for (int i = 0; i < F_HW; ++i) open |= (TM[i] & ~D[i]) != 0;
+            const u32 flags = (__any(nonempty) ? 1u : 0u) | (__any(open) ? 2u : 0u);
+            if ((tid & 63) == 0) s_any[t & 1][tid >> 6] = flags;
             __syncthreads();
             u32 any = 0;
 #pragma unroll
             for (int w = 0; w < F_NT / 64; ++w) any |= s_any[t & 1][w];
-            if (!any) break;  // nothing at distance t anywhere: nothing farther either
+            if (any != 3u) break;
         }
     }
     if (stop_after == 1) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
