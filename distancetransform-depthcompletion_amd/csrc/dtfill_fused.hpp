@@ -77,14 +77,14 @@ __device__ __forceinline__ void ring_store3(u32 *__restrict__ ring, int slot, in
     for (int i = 0; i < F_HW; ++i) p[i] = w[i];
 }
 
-// P3 of the fused pass as a function of the staged window (s_par byte codes, s_sb / s_rk rank words): tile
+// P3 of the fused pass as a function of the staged window (s_par byte codes, s_rw rank words): tile
 // pixels walk to their sources in lock-step, d, rank -> label, gather, store.  Returns whether some tile pixel
 // was undecided.  NT = threads of the calling block.
 template <int FR, int NT>
 __device__ __forceinline__ bool fused_walk_epilogue(
-    const u8 *__restrict__ s_par, const short *__restrict__ s_tab, const u64 *__restrict__ s_sb,
-    const u32 *__restrict__ s_rk, int b, int H, int W, int th, int tw, int r0, int c0, int wr0, int wc0, int ra,
-    int rb, int ca, int cb, int w0, const float *__restrict__ x, const float *__restrict__ vlist,
+    const u8 *__restrict__ s_par, const short *__restrict__ s_tab, const uint4 *__restrict__ s_rw, int b, int H,
+    int W, int th, int tw, int r0, int c0, int wr0, int wc0, int sh, const float *__restrict__ x,
+    const float *__restrict__ vlist,
     const int *__restrict__ finfo, float *__restrict__ out_depth, float *__restrict__ out_dt,
     int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
     // ---- P3: tile pixels: walk to the source, d, rank -> label, gather, store.  Each lane walks F_EB
@@ -98,6 +98,8 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     float *od = out_depth ? out_depth + fo : nullptr, *ot = out_dt ? out_dt + fo : nullptr;
     int32_t *oi = out_index ? out_index + fo : nullptr;
     const char *tab = reinterpret_cast<const char *>(s_tab);
+    const int src_base = wr0 * W + wc0;  // frame offset of window cell (0,0) (may be negative)
+    const u32 last_px = (u32)(H * W - 1);
     bool overflow = false;
     // Tile pixels in raster order over the threads: pixel p = pb + e * NT + tid, so every batch but the last
     // has all lanes busy whatever th x tw is, and a wave's stores are runs of consecutive pixels.
@@ -157,31 +159,33 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             for (int e = 0; e < F_EB; ++e) moved |= step[e];
             if (!__any(moved != 0)) break;
         }
-        int lab[F_EB], goff[F_EB], dd[F_EB];
+        int lab[F_EB], dd[F_EB];
+        u32 goff[F_EB];
         bool bad = false;
 #pragma unroll
         for (int e = 0; e < F_EB; ++e) {
-            // a decided chain ends on a source inside the in-image window; the clamps only make sure
-            // that a logic error could never become a wild global access
+            // a decided chain ends on a source inside the in-image window
             const int pr_ = (int)((u32)pos[e] / (u32)F_P), pc_ = pos[e] - pr_ * F_P;
-            const int r_ = min(max(pr_, ra), rb - 1), c_ = min(max(pc_, ca), cb - 1);
-            dd[e] = (int)__sad((u32)r_, (u32)hr[e], __sad((u32)c_, (u32)hc[e], 0u));  // L1 distance to the nearest source IS d
-            const int gj = wc0 + c_;
-            const int k = r_ * 4 + (gj >> 6) - w0;
-            const u64 below = (1ull << (gj & 63)) - 1ull;  // straight-line: one 64-bit LDS read, no select
-            lab[e] = (int)s_rk[k] + __popcll(s_sb[k] & below) + 1;
+            dd[e] = (int)__sad((u32)pr_, (u32)hr[e], __sad((u32)pc_, (u32)hc[e], 0u));  // L1 distance to the nearest source IS d
+            const int bitpos = sh + pc_;  // bit index in the row's image-aligned bit string, from word w0
+            const uint4 *rw = s_rw + pr_ * 4 + (bitpos >> 6);  // {bits lo, bits hi, rank before the word, -}
+            const u64 below = (1ull << (bitpos & 63)) - 1ull;  // one address, an 8-byte and a 4-byte read
+            lab[e] = (int)reinterpret_cast<const u32 *>(rw)[2] + __popcll(*reinterpret_cast<const u64 *>(rw) & below) + 1;
             // depth_list[label-1] (tools.py:26).  A decided pixel has label >= 1, so the numpy wrap of
             // index -1 cannot occur here; an index past the value list is numpy's IndexError.
             const int idx = lab[e] - 1;
             const bool oob = idx >= nval;
             bad |= ((ok >> e) & 1u) && oob;
-            goff[e] = oob ? 0 : (misaligned ? idx : (wr0 + r_) * W + gj);  // masks agree: the label-th value is x at the source
+            // masks agree: the label-th value is x at the source.  The min only makes sure that a logic
+            // error could never become a wild global access (an LDS index out of range reads garbage at worst).
+            const u32 at_src = (u32)(src_base + pr_ * W + pc_);
+            goff[e] = oob ? 0u : min(misaligned ? (u32)idx : at_src, last_px);
         }
         if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
         retire();  // the previous batch: its gathers had the whole walk above to arrive
 #pragma unroll
         for (int e = 0; e < F_EB; ++e) {
-            p_val[e] = gbase[(u32)goff[e]];
+            p_val[e] = gbase[goff[e]];
             p_lab[e] = lab[e];
             p_dd[e] = dd[e];
             p_opix[e] = opix[e];
@@ -195,7 +199,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
 // FR = halo = largest distance the window can decide.  gate (nullable): only frames with gate[b] != 0
 // are processed (the second, FR = 32 stage only redoes the frames the FR = 16 stage flagged).
 template <int FR>
-__global__ __launch_bounds__(F_NT) void k_fused(
+__global__ __launch_bounds__(F_NT, 4) void k_fused(
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
     const u32 *__restrict__ rowbase_s, const int *__restrict__ finfo, const float *__restrict__ vlist,
     int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
@@ -211,8 +215,9 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     const long long h_nsrc = finfo[blockIdx.y * FI_STRIDE + FI_NSRC];
     const int h_dlb = finfo[blockIdx.y * FI_STRIDE + FI_DLB];
     __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
-    __shared__ u64 s_sb[F_WHM * 4];  // source bits of the window rows, image-aligned 64-pixel words
-    __shared__ u32 s_rk[F_WHM * 4];  // sources before each of those 64-pixel words (frame raster order)
+    // per window row, the four image-aligned 64-pixel words it touches: {source bits lo, hi, sources before
+    // the word in frame raster order, -} -- one 16-byte LDS read per rank lookup
+    __shared__ uint4 s_rw[F_WHM * 4];
     __shared__ short s_tab[64];      // s_par displacement of the step enc (0 for the codes that are no step)
     __shared__ u32 s_any[2][F_NT / 64];  // per wave: did level t produce anything (double-buffered by level parity)
 
@@ -224,7 +229,6 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     const int wr0 = r0 - FR, wc0 = c0 - FR;  // image coords of window cell (0,0)
     const int WH = th + 2 * FR, WW = tw + 2 * FR;
     const int ca = max(0, -wc0), cb = min(WW, W - wc0);  // in-image window columns [ca, cb)
-    const int ra = max(0, -wr0), rb = min(WH, H - wr0);  // in-image window rows
     const int w0 = wc0 >> 6;                             // first image word column the window touches (-1 if wc0 < 0)
     const int sh = wc0 - 64 * w0;                        // window column 0 is bit sh of image word w0
 
@@ -258,8 +262,7 @@ __global__ __launch_bounds__(F_NT) void k_fused(
             // if half 1 starts later), half 1 the rest
             const bool mine = hf == 0 ? kk < 2 : (kk >= 2 && kk < 4);
             if (mine) {
-                s_sb[r * 4 + kk] = sb;
-                s_rk[r * 4 + kk] = rk;
+                s_rw[r * 4 + kk] = make_uint4((u32)sb, (u32)(sb >> 32), rk, 0u);
             }
         }
         g[6] = 0;
@@ -422,8 +425,8 @@ __global__ __launch_bounds__(F_NT) void k_fused(
     __syncthreads();
     if (stop_after == 2) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
-    const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_tab, s_sb, s_rk, b, H, W, th, tw, r0, c0, wr0, wc0, ra, rb, ca, cb,
-                                                        w0, x, vlist, finfo, out_depth, out_dt, out_index, frame_status);
+    const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_tab, s_rw, b, H, W, th, tw, r0, c0, wr0, wc0, sh, x, vlist,
+                                                        finfo, out_depth, out_dt, out_index, frame_status);
     if (overflow) {
         fflag[b] = 1;  // same-value race
         if (FR == 32) atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);  // last fused stage: general path next
