@@ -121,7 +121,8 @@ __device__ __forceinline__ bool fused_walk_epilogue(
         }
     };
     for (int pb = 0; pb < npx; pb += NT * F_EB) {
-        int pos[F_EB], code[F_EB], hr[F_EB], hc[F_EB];  // pos = row * F_P + col: byte index in s_par
+        int pos[F_EB], code[F_EB];  // pos = row * F_P + col: byte index in s_par
+        u32 home[F_EB];             // window row << 16 | window column of the walker's own pixel
         u32 opix[F_EB];
         u32 ok = 0;
 #pragma unroll
@@ -131,11 +132,10 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             // p / tw: (p + 0.5) / tw is at least 0.5 / tw away from an integer, far above float rounding
             // for p < 2^14, tw < 2^8
             const int tr = (int)(((float)pc + 0.5f) * inv_tw);
-            const int tc = pc - tr * tw;
-            hr[e] = FR + tr;
-            hc[e] = FR + tc;
-            opix[e] = (u32)((r0 + tr) * W + c0 + tc);
-            pos[e] = hr[e] * F_P + hc[e];
+            const int tc = pc - __mul24(tr, tw);
+            home[e] = (u32)(FR + tr) << 16 | (u32)(FR + tc);
+            opix[e] = (u32)(__mul24(r0 + tr, W) + c0 + tc);  // 24-bit multiplies are full rate (H, W < 8192)
+            pos[e] = __mul24(FR + tr, F_P) + FR + tc;
             code[e] = s_par[pos[e]];
             ok |= (p < npx && code[e] != F_NONE) ? (1u << e) : 0u;
             overflow |= p < npx && code[e] == F_NONE;  // undecidable here: the frame takes the general path
@@ -165,8 +165,9 @@ __device__ __forceinline__ bool fused_walk_epilogue(
 #pragma unroll
         for (int e = 0; e < F_EB; ++e) {
             // a decided chain ends on a source inside the in-image window
-            const int pr_ = (int)((u32)pos[e] / (u32)F_P), pc_ = pos[e] - pr_ * F_P;
-            dd[e] = (int)__sad((u32)pr_, (u32)hr[e], __sad((u32)pc_, (u32)hc[e], 0u));  // L1 distance to the nearest source IS d
+            const int pr_ = (int)((u32)pos[e] / (u32)F_P), pc_ = pos[e] - __mul24(pr_, F_P);
+            // L1 distance to the nearest source IS d: |drow| + |dcol| of the two 16-bit halves in one instruction
+            dd[e] = (int)__builtin_amdgcn_sad_u16((u32)pr_ << 16 | (u32)pc_, home[e], 0u);
             const int bitpos = sh + pc_;  // bit index in the row's image-aligned bit string, from word w0
             const uint4 *rw = s_rw + pr_ * 4 + (bitpos >> 6);  // {bits lo, bits hi, rank before the word, -}
             const u64 below = (1ull << (bitpos & 63)) - 1ull;  // one address, an 8-byte and a 4-byte read
@@ -178,7 +179,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             bad |= ((ok >> e) & 1u) && oob;
             // masks agree: the label-th value is x at the source.  The min only makes sure that a logic
             // error could never become a wild global access (an LDS index out of range reads garbage at worst).
-            const u32 at_src = (u32)(src_base + pr_ * W + pc_);
+            const u32 at_src = (u32)(src_base + __mul24(pr_, W) + pc_);
             goff[e] = oob ? 0u : min(misaligned ? (u32)idx : at_src, last_px);
         }
         if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
