@@ -63,6 +63,14 @@ __device__ __forceinline__ void tap_step(const u32 (&src)[5], u32 (&taken)[F_HW]
     }
 }
 
+// 24-bit multiply the optimiser cannot see through: written as a plain product it folds the following shift
+// into the constant, which then no longer fits 24 bits and becomes a quarter-rate v_mul_lo_u32
+__device__ __forceinline__ u32 mul_u24_opaque(u32 a, u32 b) {
+    u32 r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // the lane's three words of a ring row plus one neighbour word on each side (pads / other half)
 __device__ __forceinline__ void ring_load5(const u32 *__restrict__ ring, int slot, int plane, int row, int wb,
                                            u32 (&a)[5]) {
@@ -165,7 +173,9 @@ __device__ __forceinline__ bool fused_walk_epilogue(
 #pragma unroll
         for (int e = 0; e < F_EB; ++e) {
             // a decided chain ends on a source inside the in-image window
-            const int pr_ = (int)((u32)pos[e] / (u32)F_P), pc_ = pos[e] - __mul24(pr_, F_P);
+            // pos / F_P in float: (pos + 0.5) / F_P is >= 0.5 / F_P away from an integer, pos < 2^15 (three full-rate
+            // instructions; the integer division is a quarter-rate v_mul_hi_u32)
+            const int pr_ = (int)(((float)pos[e] + 0.5f) * (1.0f / (float)F_P)), pc_ = pos[e] - __mul24(pr_, F_P);
             // L1 distance to the nearest source IS d: |drow| + |dcol| of the two 16-bit halves in one instruction
             dd[e] = (int)__builtin_amdgcn_sad_u16((u32)pr_ << 16 | (u32)pc_, home[e], 0u);
             const int bitpos = sh + pc_;  // bit index in the row's image-aligned bit string, from word w0
@@ -402,7 +412,8 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     if (stop_after == 1) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
     // ---- P2: un-slice the code planes of this half row into bytes, 4 pixels per step.
-    // ((nibble * 0x00204081) & 0x01010101) spreads bits 0..3 of the nibble to the low bits of 4 bytes.
+    // ((nibble * 0x00204081) & 0x01010101) spreads bits 0..3 of the nibble to the low bits of 4 bytes
+    // (a 24-bit multiply: full rate, v_mul_lo_u32 is quarter rate).
     u8 *s_par = reinterpret_cast<u8 *>(s_ring);
     __syncthreads();  // the ring is dead for everybody before its memory becomes s_par
     {
@@ -415,11 +426,11 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     const u32 nib = (C[j][i] >> (4 * q)) & 0xFu;
-                    v |= ((nib * 0x00204081u) & 0x01010101u) << (j + 1);  // byte = 2 * enc
+                    v |= (mul_u24_opaque(nib, 0x00204081u) & 0x01010101u) << (j + 1);  // byte = 2 * enc
                 }
                 // undecided pixels (not in D): no plane bit is set; give them F_NONE
-                const u32 und = ((~D[i] >> (4 * q)) & 0xFu) * 0x00204081u & 0x01010101u;
-                prow[i * 8 + q] = v | und * (u32)F_NONE;
+                const u32 und = mul_u24_opaque((~D[i] >> (4 * q)) & 0xFu, 0x00204081u) & 0x01010101u;
+                prow[i * 8 + q] = v | __umul24(und, (u32)F_NONE);
             }
         }
     }
