@@ -151,21 +151,26 @@ __device__ __forceinline__ bool fused_walk_epilogue(
         // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
         // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
         // overlap.  Two hops between "everybody arrived?" checks.
-        for (int hop = 0; hop < FR; hop += 2) {
+        for (int hop = 0; hop < FR + 2; hop += 2) {
             int step[F_EB];
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
+            for (int e = 0; e < F_EB; ++e) step[e] = *reinterpret_cast<const short *>(tab + code[e]);
+            // everybody arrived? -- asked right after the (cheap, broadcast) table read, so the last trip
+            // through the loop costs those 8 reads and not two more full hops
+            int moving = 0;
 #pragma unroll
-                for (int e = 0; e < F_EB; ++e) step[e] = *reinterpret_cast<const short *>(tab + code[e]);
+            for (int e = 0; e < F_EB; ++e) moving |= step[e];
+            if (!__any(moving != 0)) break;
 #pragma unroll
-                for (int e = 0; e < F_EB; ++e) pos[e] += step[e];
+            for (int e = 0; e < F_EB; ++e) pos[e] += step[e];
 #pragma unroll
-                for (int e = 0; e < F_EB; ++e) code[e] = s_par[pos[e]];
-            }
-            int moved = 0;  // a walker whose last step was (0,0) has arrived
+            for (int e = 0; e < F_EB; ++e) code[e] = s_par[pos[e]];
 #pragma unroll
-            for (int e = 0; e < F_EB; ++e) moved |= step[e];
-            if (!__any(moved != 0)) break;
+            for (int e = 0; e < F_EB; ++e) step[e] = *reinterpret_cast<const short *>(tab + code[e]);
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) pos[e] += step[e];
+#pragma unroll
+            for (int e = 0; e < F_EB; ++e) code[e] = s_par[pos[e]];
         }
         int lab[F_EB], dd[F_EB];
         u32 goff[F_EB];
