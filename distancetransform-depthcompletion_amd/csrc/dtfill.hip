@@ -130,6 +130,17 @@ constexpr int NK_L1 = 8;
 const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame",   "k_fused", "k_colscan",
                                      "k_skew", "k_rowscan", "k_exit",  "k_final"};
 
+// k_mask4 when the rows can be read 16 bytes at a time, k_mask otherwise (same outputs)
+void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, float val_thr, const Carve &c, hipStream_t st) {
+    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        k_mask4<<<dim3((H + 3) / 4, B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s,
+                                                      c.wpre_v, c.rowcnt_s, c.rowcnt_v);
+    else
+        k_mask<<<dim3((H + 4 * M_RPW - 1) / (4 * M_RPW), B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits,
+                                                                          c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s,
+                                                                          c.rowcnt_v);
+}
+
 int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, float *out_depth,
            float *out_dt, int32_t *out_index, int32_t *frame_status, void *workspace, unsigned flags,
            hipStream_t st, hipEvent_t *ev) {
@@ -149,8 +160,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         if (ev) (void)hipEventRecord(ev[k++], st);
     };
     mark();
-    k_mask<<<dim3((H + 4 * M_RPW - 1) / (4 * M_RPW), B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits,
-                                                c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v);
+    launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s,
                                c.rowbase_v, c.finfo, c.vlist, c.fflag, c.fflag2, status, general_only ? 1 : 0);
@@ -215,8 +225,7 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         if (ev) (void)hipEventRecord(ev[k++], st);
     };
     mark();
-    k_mask<<<dim3((H + 4 * M_RPW - 1) / (4 * M_RPW), B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits,
-                                                                      c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v);
+    launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
                                c.finfo, c.vlist, c.fflag, c.fflag2, status, 0);

@@ -88,6 +88,86 @@ __global__ __launch_bounds__(256) void k_mask(const float *__restrict__ x, int H
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_mask4: the same outputs for rows whose pixels can be read 16 bytes at a time (W % 4 == 0, 16-byte aligned
+// frames): one wave per row, a lane reads 4 consecutive pixels, 256 pixels = four 64-pixel words per load
+// instruction, and all loads of a row (up to M4_NC at a time) are in flight together.  A lane's four predicate
+// bits form a nibble; the 16 lanes of a DPP row hold one word, combined with four DPP OR steps.
+// ------------------------------------------------------------------------------------------------
+constexpr int M4_NC = 8;  // 256-pixel chunks per batch (2048 pixels)
+
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_or(u32 v) {  // v | v of the lane CTRL pairs it with (inside a row of 16)
+    return v | (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+// the 64-pixel word of this lane's 16-lane row from the lanes' nibbles (lane i of the row owns bits 4i..4i+3)
+__device__ __forceinline__ u64 row_word(u32 nib, int lane) {
+    u32 part = nib << (4 * (lane & 7));  // lanes 0-7 of the row build the low half, lanes 8-15 the high half
+    part = dpp_or<0xB1>(part);           // quad_perm [1,0,3,2]
+    part = dpp_or<0x4E>(part);           // quad_perm [2,3,0,1]
+    part = dpp_or<0x141>(part);          // row_half_mirror: now every lane has its half-row's 32 bits
+    const u32 other = (u32)__builtin_amdgcn_update_dpp(0, (int)part, 0x140, 0xF, 0xF, false);  // row_mirror
+    return (lane & 8) ? ((u64)part << 32 | other) : ((u64)other << 32 | part);
+}
+
+__global__ __launch_bounds__(256) void k_mask4(const float *__restrict__ x, int H, int W, int Wd, float src_thr,
+                                               float val_thr, u64 *__restrict__ srcbits, u64 *__restrict__ valbits,
+                                               u16 *__restrict__ wpre_s, u16 *__restrict__ wpre_v,
+                                               u32 *__restrict__ rowcnt_s, u32 *__restrict__ rowcnt_v) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (i >= H) return;
+    const float4 *row = reinterpret_cast<const float4 *>(x + ((size_t)b * H + i) * W);
+    const size_t wrow = ((size_t)b * H + i) * Wd;
+    const int w_in_chunk = lane >> 4;  // which of the chunk's four words this lane's row builds
+    u32 run_s = 0, run_v = 0, mis = 0;  // wave-uniform
+    const int nchunk = (W + 255) >> 8;
+    for (int c0 = 0; c0 < nchunk; c0 += M4_NC) {
+        float4 v[M4_NC];
+#pragma unroll
+        for (int u = 0; u < M4_NC; ++u) {
+            const int px = ((c0 + u) << 8) + 4 * lane;
+            v[u] = (c0 + u < nchunk && px < W) ? row[px >> 2] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < M4_NC; ++u) {
+            if (c0 + u >= nchunk) break;  // wave-uniform
+            const int px = ((c0 + u) << 8) + 4 * lane;
+            const bool in = px < W;  // W % 4 == 0: a lane's four pixels are inside or outside together
+            const float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            u32 ns = 0, nv = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ns |= (in && !((1.0f - f[q]) > src_thr)) ? (1u << q) : 0u;
+                nv |= (in && (f[q] > val_thr)) ? (1u << q) : 0u;
+            }
+            const u64 ws = row_word(ns, lane), wv = row_word(nv, lane);
+            const u32 cs = (u32)__popcll(ws), cv = (u32)__popcll(wv);
+            // counts of the chunk's four words (every lane of a row holds its word's count)
+            const u32 s0 = __builtin_amdgcn_readlane(cs, 0), s1 = __builtin_amdgcn_readlane(cs, 16),
+                      s2 = __builtin_amdgcn_readlane(cs, 32), s3 = __builtin_amdgcn_readlane(cs, 48);
+            const u32 v0 = __builtin_amdgcn_readlane(cv, 0), v1 = __builtin_amdgcn_readlane(cv, 16),
+                      v2 = __builtin_amdgcn_readlane(cv, 32), v3 = __builtin_amdgcn_readlane(cv, 48);
+            const u32 pre_s = run_s + (w_in_chunk > 0 ? s0 : 0u) + (w_in_chunk > 1 ? s1 : 0u) + (w_in_chunk > 2 ? s2 : 0u);
+            const u32 pre_v = run_v + (w_in_chunk > 0 ? v0 : 0u) + (w_in_chunk > 1 ? v1 : 0u) + (w_in_chunk > 2 ? v2 : 0u);
+            mis |= __any(ws != wv) ? 1u : 0u;
+            const int k = ((c0 + u) << 2) + w_in_chunk;  // word index in the row
+            if ((lane & 15) == 0 && k < Wd) {             // one lane per word: four adjacent words per store
+                srcbits[wrow + k] = ws;
+                valbits[wrow + k] = wv;
+                wpre_s[wrow + k] = (u16)pre_s;
+                wpre_v[wrow + k] = (u16)pre_v;
+            }
+            run_s += s0 + s1 + s2 + s3;
+            run_v += v0 + v1 + v2 + v3;
+        }
+    }
+    if (lane == 0) {
+        rowcnt_s[(size_t)b * H + i] = run_s;
+        rowcnt_v[(size_t)b * H + i] = run_v | (mis ? 0x80000000u : 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_frame: one workgroup per frame.  Exclusive scan of the row counts = raster rank of the first
 // source / value pixel of every row: cv2's label init (k=1; every zero pixel gets k++) and numpy's
 // boolean compaction x[with_value] (tools.py:24).  The value list is only materialised when the two
