@@ -123,9 +123,10 @@ __device__ __forceinline__ bool fused_walk_epilogue(
 #pragma unroll
         for (int e = 0; e < F_EB; ++e) {
             if (!((p_ok >> e) & 1u)) continue;
-            if (oi) oi[p_opix[e]] = p_lab[e];
-            if (ot) ot[p_opix[e]] = (float)p_dd[e];
-            if (od) od[p_opix[e]] = p_val[e];
+            // p_opix is a BYTE offset (< 2^32: a frame has < 2^26 pixels): scalar base + 32-bit vector offset
+            if (oi) *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(oi) + p_opix[e]) = p_lab[e];
+            if (ot) *reinterpret_cast<float *>(reinterpret_cast<char *>(ot) + p_opix[e]) = (float)p_dd[e];
+            if (od) *reinterpret_cast<float *>(reinterpret_cast<char *>(od) + p_opix[e]) = p_val[e];
         }
     };
     for (int pb = 0; pb < npx; pb += NT * F_EB) {
@@ -142,7 +143,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             const int tr = (int)(((float)pc + 0.5f) * inv_tw);
             const int tc = pc - __mul24(tr, tw);
             home[e] = (u32)(FR + tr) << 16 | (u32)(FR + tc);
-            opix[e] = (u32)(__mul24(r0 + tr, W) + c0 + tc);  // 24-bit multiplies are full rate (H, W < 8192)
+            opix[e] = (u32)(__mul24(r0 + tr, W) + c0 + tc) << 2;  // byte offset; 24-bit multiplies are full rate (H, W < 8192)
             pos[e] = __mul24(FR + tr, F_P) + FR + tc;
             code[e] = s_par[pos[e]];
             ok |= (p < npx && code[e] != F_NONE) ? (1u << e) : 0u;
@@ -195,13 +196,13 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             // masks agree: the label-th value is x at the source.  The min only makes sure that a logic
             // error could never become a wild global access (an LDS index out of range reads garbage at worst).
             const u32 at_src = (u32)(src_base + __mul24(pr_, W) + pc_);
-            goff[e] = oob ? 0u : min(misaligned ? (u32)idx : at_src, last_px);
+            goff[e] = (oob ? 0u : min(misaligned ? (u32)idx : at_src, last_px)) << 2;  // byte offset
         }
         if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
         retire();  // the previous batch: its gathers had the whole walk above to arrive
 #pragma unroll
         for (int e = 0; e < F_EB; ++e) {
-            p_val[e] = gbase[goff[e]];
+            p_val[e] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(gbase) + goff[e]);
             p_lab[e] = lab[e];
             p_dd[e] = dd[e];
             p_opix[e] = opix[e];
