@@ -75,7 +75,9 @@ namespace {
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 struct Carve {
-    u16 *gu, *g, *dB, *dl;
+    u16 *gu, *g, *dB;
+    u8 *planes;          // k_rowscan -> k_exit: four bit planes (d & 1, d >> 1 & 1, d >> 2 & 1, live), Wd * 8 bytes per row
+    size_t plane_bytes;  // bytes of one plane
     u32 *exitp;
     u64 *srcbits, *valbits;
     u16 *wpre_s, *wpre_v;
@@ -114,7 +116,8 @@ Carve carve(void *ws, int B, int H, int W) {
     c.gu = (u16 *)take(N * 2);
     c.g = (u16 *)take(N * 2);
     c.dB = (u16 *)take(N * 2);
-    c.dl = (u16 *)take(N * 2);
+    c.plane_bytes = align256(NW * 8);
+    c.planes = (u8 *)take(4 * c.plane_bytes);
     c.exitp = (u32 *)take(N * 4);
     c.vlist = (float *)take(N * 4);
     c.total = off;
@@ -195,11 +198,12 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const size_t per_wave = (size_t)nseg * 512 * sizeof(int);  // <= 32 KiB at W = 8191
         const int wpb = (int)max((size_t)1, min((size_t)4, (size_t)65536 / per_wave));
         k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag2, H, W, nseg,
-                                                                              c.dl);
+                                                                              Wd * 8, c.planes, c.plane_bytes, out_dt);
         mark();
         {
             const int etx = (W + X_T - 1) / X_T, ety = (H + X_T - 1) / X_T;
-            k_exit<<<dim3(etx * ety, B), X_NT, 0, st>>>(c.dl, c.fflag2, H, W, etx, c.exitp, out_dt, exit_stop);
+            k_exit<<<dim3(etx * ety, B), X_NT, 0, st>>>(c.planes, c.plane_bytes, Wd * 8, c.srcbits, Wd, c.finfo, c.fflag2, H,
+                                                        W, etx, c.exitp, exit_stop);
         }
         mark();
         k_final<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(

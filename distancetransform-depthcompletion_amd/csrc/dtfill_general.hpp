@@ -210,9 +210,13 @@ __device__ __forceinline__ void load8(const u16 *__restrict__ row, int idx0, int
     for (int q = 0; q < 8; ++q) v[q] = v[q] == INF16 ? BIG : v[q];
 }
 
+// Output: the float distance map (the last consumer of the full d) and four bit planes for k_exit, one byte
+// per 8 pixels and plane: d & 1, d >> 1 & 1, d >> 2 & 1, live (plane p of row i starts at
+// planes + p * plane_bytes + (b * H + i) * Wp; Wp = bytes per row, a multiple of 8).
 __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, const u16 *__restrict__ gu,
                                                  const u16 *__restrict__ dB, const int *__restrict__ fflag,
-                                                 int H, int W, int nseg, u16 *__restrict__ dl) {
+                                                 int H, int W, int nseg, int Wp, u8 *__restrict__ planes,
+                                                 size_t plane_bytes, float *__restrict__ out_dt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar row index
     const int i = blockIdx.x * (blockDim.x >> 6) + wave, b = blockIdx.y;
@@ -262,117 +266,196 @@ __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, cons
         const int es = min(wave_excl_suffix_min(ms, lane), carry_b);
         int dbv[8];
         load8(dBrow, idx0, W, vec, dbv);
-        u32 out[8];
+        u32 p0 = 0, p1 = 0, p2 = 0, pl = 0;
+        float fd[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int d = min(ls[q], es) - (idx0 + q);
             const bool live = (fl[q] && av[q] == d) || dbv[q] == d;
-            out[q] = d >= DL_NONE ? (u32)DL_NONE : (u32)(d | (live ? DL_LIVE : 0));  // DL_NONE: no source in the frame
+            const bool inw = idx0 + q < W;
+            p0 |= (inw ? (u32)d & 1u : 0u) << q;
+            p1 |= (inw ? ((u32)d >> 1) & 1u : 0u) << q;
+            p2 |= (inw ? ((u32)d >> 2) & 1u : 0u) << q;
+            pl |= ((inw && live) ? 1u : 0u) << q;
+            fd[q] = d >= DL_NONE ? 8192.0f : (float)d;  // no source in the frame: float(INIT_DIST0 * 2^-16) == 8192.0f
         }
         carry_b = __shfl(min(ms, es), 0);
-        if (vec && idx0 + 8 <= W) {
-            uint4 o;
-            o.x = out[0] | out[1] << 16; o.y = out[2] | out[3] << 16; o.z = out[4] | out[5] << 16; o.w = out[6] | out[7] << 16;
-            *reinterpret_cast<uint4 *>(dl + ro + idx0) = o;
-        } else {
+        const int byte = idx0 >> 3;
+        if (byte < Wp) {
+            u8 *pb = planes + ((size_t)b * H + i) * Wp + byte;
+            pb[0] = (u8)p0;
+            pb[plane_bytes] = (u8)p1;
+            pb[2 * plane_bytes] = (u8)p2;
+            pb[3 * plane_bytes] = (u8)pl;
+        }
+        if (out_dt) {
+            if (vec && (reinterpret_cast<size_t>(out_dt) & 15) == 0 && idx0 + 8 <= W) {  // W % 8 == 0: aligned float rows
+                float4 *o = reinterpret_cast<float4 *>(out_dt + ro + idx0);
+                o[0] = make_float4(fd[0], fd[1], fd[2], fd[3]);
+                o[1] = make_float4(fd[4], fd[5], fd[6], fd[7]);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (idx0 + q < W) dl[ro + idx0 + q] = (u16)out[q];
+                for (int q = 0; q < 8; ++q)
+                    if (idx0 + q < W) out_dt[ro + idx0 + q] = fd[q];
+            }
         }
     }
 }
 
 constexpr int G_PPT = 16;  // pixels per thread in k_final (keeps its no-op grid small)
 
-// k_exit: one block per 128 x 128 tile.  Loads the tile of dl (d | live<<15) with a 2-cell halo into LDS,
-// applies the 5x5 parent rule there, and resolves the chains inside the tile by pointer doubling in LDS
-// (every cell does the same work each round: no divergent walks, and the number of rounds is log2 of the
-// longest in-tile chain, whatever the distances are).  A cell is terminal if it is a source, has no
-// parent, or its parent lies outside the tile.  Result per pixel: an exit pointer
+// k_exit: one block per 128 x 128 tile.  Loads the tile's bit planes (d mod 8, live -- from k_rowscan -- and
+// the source bits) with a 2-cell halo into LDS, applies the 5x5 parent rule BIT-SLICED, 32 pixels per
+// operation, and resolves the chains inside the tile by pointer doubling in LDS (every cell does the same work
+// each round: no divergent walks, and the number of rounds is log of the longest in-tile chain, whatever
+// the distances are).  A cell is terminal if it is a source, has no parent, or its parent lies outside the
+// tile.  Result per pixel: an exit pointer
 //   bit 31 set : the chain's root source, pixel index in the low bits
 //   0x7FFFFFFF : no source in the frame
 //   otherwise  : pixel index (another tile) where the chain continues
-// Also stores the float distance map (the last consumer of d).
+//
+// Parent rule on d mod 8: a tap (di,dj) of weight w = |di|+|dj| <= 3 matches iff d(r) + w == d(q); d is the
+// exact L1 distance, so |d(r) - d(q)| <= w and d(r) + w - d(q) lies in [0, 6]: it is 0 iff it is 0 mod 8.
 constexpr int X_T = 128;             // tile edge
 constexpr int X_NT = 1024;           // threads per block
-constexpr int X_P = X_T + 4;         // dl tile pitch (2-cell halo each side)
+constexpr int X_P = X_T + 4;         // rows of the plane tile (2-cell halo above and below)
+constexpr int X_CP = X_T + 4;        // s_code row pitch in bytes: 33 dwords (odd) -> the un-slice stores spread over the banks
 constexpr u32 X_ROOT = 0x80000000u;  // exit pointer: resolved to a root
 constexpr u32 X_NONE = 0x7FFFFFFFu;  // exit pointer: frame without sources
-constexpr int X_BORDER = 0x3FF0;     // dl value outside the image: (v & mask) + w never equals a d | live<<15
+constexpr int X_NPL = 6;             // planes in LDS: d bit 0, 1, 2, live, source, in-image
+constexpr int X_RW = 7;              // words per plane row in LDS: image words c0/32 - 1 .. c0/32 + 4, + 1 pad (odd stride)
 
-__global__ __launch_bounds__(X_NT) void k_exit(const u16 *__restrict__ dl, const int *__restrict__ fflag, int H,
-                                              int W, int tiles_x, u32 *__restrict__ exitp,
-                                              float *__restrict__ out_dt, int stop_after) {
-    __shared__ __attribute__((aligned(16))) u16 s_big[X_P * X_P];  // dl tile + halo; later the pointers (X_T*X_T)
-    __shared__ u8 s_code[X_T * X_T];
+// bits of the pixels (column + DJ) of the word `cur` of a row (prev / next = the words left / right of it)
+template <int DJ>
+__device__ __forceinline__ u32 xshift(u32 prev, u32 cur, u32 next) {
+    if (DJ == 0) return cur;
+    if (DJ > 0) return __builtin_amdgcn_alignbit(next, cur, DJ);
+    return __builtin_amdgcn_alignbit(cur, prev, 32 + DJ);
+}
+
+// One tap of the parent rule for 32 pixels.  The candidate r = q + (DI, DJ) has the planes row[...] (three
+// words each: left, this, right).  FWD: r must be live.  First match wins: sel = match & ~taken.
+template <int DJ, int WGT, bool FWD, int CODE>
+__device__ __forceinline__ void exit_tap(const u32 (&a0)[3], const u32 (&a1)[3], const u32 (&a2)[3], const u32 (&lv)[3],
+                                         const u32 (&vd)[3], u32 b0, u32 b1, u32 b2, u32 &taken, u32 (&T)[4]) {
+    const u32 x0 = xshift<DJ>(a0[0], a0[1], a0[2]), x1 = xshift<DJ>(a1[0], a1[1], a1[2]),
+              x2 = xshift<DJ>(a2[0], a2[1], a2[2]);
+    u32 s0, s1, s2;  // (d(r) + WGT) mod 8
+    if (WGT == 1) {
+        s0 = ~x0; s1 = x1 ^ x0; s2 = x2 ^ (x1 & x0);
+    } else if (WGT == 2) {
+        s0 = x0; s1 = ~x1; s2 = x2 ^ x1;
+    } else {
+        s0 = ~x0; s1 = ~(x1 ^ x0); s2 = x2 ^ (x1 | x0);  // +1 then +2: carry into bit 2 iff x1 | x0
+    }
+    u32 m = ~((s0 ^ b0) | (s1 ^ b1) | (s2 ^ b2)) & xshift<DJ>(vd[0], vd[1], vd[2]);
+    if (FWD) m &= xshift<DJ>(lv[0], lv[1], lv[2]);
+    const u32 sel = m & ~taken;
+    taken |= m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (CODE & (1 << j)) T[j] |= sel;
+}
+
+__global__ __launch_bounds__(X_NT) void k_exit(const u8 *__restrict__ planes, size_t plane_bytes, int Wp,
+                                              const u64 *__restrict__ srcbits, int Wd,
+                                              const int *__restrict__ finfo, const int *__restrict__ fflag, int H,
+                                              int W, int tiles_x, u32 *__restrict__ exitp, int stop_after) {
+    __shared__ __attribute__((aligned(16))) u16 s_big[X_T * X_T];  // first the planes (22 KB), later the pointers
+    __shared__ __attribute__((aligned(16))) u8 s_code[X_T * X_CP];
+    static_assert(X_NPL * X_P * X_RW * 4 <= X_T * X_T * 2, "the planes must fit under the pointers");
     const int b = blockIdx.y;
     if (!fflag[b]) return;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * X_T, c0 = tx * X_T;
     const size_t fo = (size_t)b * H * W;
-    const u16 *dlf = dl + fo;
     const int tid = threadIdx.x;
+    u32 *s_pl = reinterpret_cast<u32 *>(s_big);  // [plane][row][X_RW]
+    const bool has_src = finfo[b * FI_STRIDE + FI_NSRC] != 0;
 
-    {   // tile + halo: one wave per row, lanes along the row (coalesced, no divisions); the loads of 8 rows
-        // (24 per lane) are issued before the first LDS store, so the memory round trips overlap
-        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar row index
-        for (int rb = wave; rb < X_P; rb += (X_NT / 64) * 8) {
-            u16 v[8][3];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = rb + (X_NT / 64) * u;
-                const int gi = r0 + r - 2;
-                const bool rin = r < X_P && gi >= 0 && gi < H;
-                const u16 *src = dlf + (size_t)(rin ? gi : 0) * W;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int c = lane + 64 * q, gj = c0 + c - 2;
-                    v[u][q] = (rin && c < X_P && gj >= 0 && gj < W) ? src[gj] : (u16)X_BORDER;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = rb + (X_NT / 64) * u;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int c = lane + 64 * q;
-                    if (r < X_P && c < X_P) s_big[r * X_P + c] = v[u][q];
-                }
-            }
+    // plane tile: rows r0-2 .. r0+129, image words c0/32 - 1 .. c0/32 + 4 (32-bit views of the byte / u64 arrays)
+    for (int k = tid; k < X_NPL * X_P * 6; k += X_NT) {
+        const int pl = k / (X_P * 6), rem = k - pl * (X_P * 6);
+        const int r = rem / 6, w = rem - r * 6;
+        const int gi = r0 + r - 2, wi = (c0 >> 5) - 1 + w;
+        u32 v = 0;
+        if (gi >= 0 && gi < H && wi >= 0 && wi * 32 < W) {
+            if (pl < 4)
+                v = reinterpret_cast<const u32 *>(planes + pl * plane_bytes + ((size_t)b * H + gi) * Wp)[wi];
+            else if (pl == 4)
+                v = reinterpret_cast<const u32 *>(srcbits + ((size_t)b * H + gi) * Wd)[wi];
+            const int up = min(W - wi * 32, 32);  // in-image columns of this word: [0, up)
+            const u32 inimg = up >= 32 ? 0xFFFFFFFFu : ((1u << up) - 1u);
+            v = pl == 5 ? inimg : (v & inimg);
         }
+        s_pl[(pl * X_P + r) * X_RW + w] = v;
     }
     __syncthreads();
     if (stop_after == 0) return;  // timing-only (DTFILL_EXIT_STOP)
-    // parent rule, straight-line: tap t forward for live cells, the negated tap for the others; keep the
-    // code format of tap_decode (t | backward << 3)
-    for (int k = tid; k < X_T * X_T; k += X_NT) {
-        const int r = k >> 7, c = k & (X_T - 1);
-        const u16 *p = s_big + (r + 2) * X_P + c + 2;
-        const int v = *p;
-        const int d = v & DL_DMASK;
-        const int live = v >> 15;
-        const int sgn = live ? 1 : -1;
-        const int msk = live ? 0xFFFF : DL_DMASK;
-        int t_sel = -1;
+    // parent rule: thread (row, word) handles 32 pixels; code = tap t (forward, live pixels) or 8 | t (the
+    // negated tap, the others), the format tap_decode reads
+    u32 T[4] = {0, 0, 0, 0}, found = 0, qsrc = 0, qin = 0;
+    const int pr = tid >> 2, pw = tid & 3;  // tile row, tile word (tid < 512)
+    if (tid < X_T * 4) {
+        auto ld3 = [&](int pl, int row, u32 (&o)[3]) {  // words pw-1, pw, pw+1 of tile = LDS words pw, pw+1, pw+2
+            const u32 *p = s_pl + (pl * X_P + row) * X_RW + pw;
+            o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+        };
+        const int qrow = pr + 2;
+        const u32 *qp = s_pl + qrow * X_RW + pw + 1;
+        const u32 b0 = qp[0], b1 = qp[X_P * X_RW], b2 = qp[2 * X_P * X_RW], qlive = qp[3 * X_P * X_RW];
+        qsrc = qp[4 * X_P * X_RW];
+        qin = qp[5 * X_P * X_RW];
+        u32 takenF = ~(qin & ~qsrc & qlive), takenB = ~(qin & ~qsrc & ~qlive);
+        u32 a0[3], a1[3], a2[3], lv[3], vd[3];
+        // cv2 tap order: (-2,-1) (-2,+1) (-1,-2) (-1,-1) (-1,0) (-1,+1) (-1,+2) (0,-1); backward = the negated
+        // offsets in the same order.  The two chains are independent (live / non-live pixels), each keeps its order.
+        ld3(0, qrow - 2, a0); ld3(1, qrow - 2, a1); ld3(2, qrow - 2, a2); ld3(3, qrow - 2, lv); ld3(5, qrow - 2, vd);
+        exit_tap<-1, 3, true, 0>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, T);
+        exit_tap<+1, 3, true, 1>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, T);
+        ld3(0, qrow - 1, a0); ld3(1, qrow - 1, a1); ld3(2, qrow - 1, a2); ld3(3, qrow - 1, lv); ld3(5, qrow - 1, vd);
+        exit_tap<-2, 3, true, 2>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, T);
+        exit_tap<-1, 2, true, 3>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, T);
+        exit_tap<0, 1, true, 4>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, T);
+        exit_tap<+1, 2, true, 5>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, T);
+        exit_tap<+2, 3, true, 6>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, T);
+        u32 z0[3], z1[3], z2[3], zv[3];  // this row: last forward tap now, last backward tap at the end
+        ld3(0, qrow, z0); ld3(1, qrow, z1); ld3(2, qrow, z2); ld3(3, qrow, lv); ld3(5, qrow, zv);
+        exit_tap<-1, 1, true, 7>(z0, z1, z2, lv, zv, b0, b1, b2, takenF, T);
+        ld3(0, qrow + 2, a0); ld3(1, qrow + 2, a1); ld3(2, qrow + 2, a2); ld3(5, qrow + 2, vd);
+        exit_tap<+1, 3, false, 8 | 0>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, T);
+        exit_tap<-1, 3, false, 8 | 1>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, T);
+        ld3(0, qrow + 1, a0); ld3(1, qrow + 1, a1); ld3(2, qrow + 1, a2); ld3(5, qrow + 1, vd);
+        exit_tap<+2, 3, false, 8 | 2>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, T);
+        exit_tap<+1, 2, false, 8 | 3>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, T);
+        exit_tap<0, 1, false, 8 | 4>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, T);
+        exit_tap<-1, 2, false, 8 | 5>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, T);
+        exit_tap<-2, 3, false, 8 | 6>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, T);
+        exit_tap<+1, 1, false, 8 | 7>(z0, z1, z2, lv, zv, b0, b1, b2, takenB, T);
+        const u32 open = qin & ~qsrc;
+        found = has_src ? ((takenF & open & qlive) | (takenB & open & ~qlive)) : 0u;
+        if (!has_src) qsrc = T[0] = T[1] = T[2] = T[3] = 0;  // frame without sources: every cell PAR_NONE
+    }
+    __syncthreads();  // everybody has read the planes it needs (s_code is separate memory, written next)
+    if (tid < X_T * 4) {
+        // un-slice: 4 pixels per step; byte = tap code, PAR_NONE (0xFE) without a parent, PAR_SRC (0xFF) for a source
+        u32 *crow = reinterpret_cast<u32 *>(s_code + pr * X_CP + pw * 32);
 #pragma unroll
-        for (int t = 7; t >= 0; --t) {  // descending: the FIRST matching tap is kept
-            const int nv = p[sgn * (TAP_DI(t) * X_P + TAP_DJ(t))];
-            t_sel = ((nv & msk) + TAP_W(t) == v) ? t : t_sel;
+        for (int q = 0; q < 8; ++q) {
+            u32 v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v |= (__umul24((T[j] >> (4 * q)) & 0xFu, 0x00204081u) & 0x01010101u) << j;
+            const u32 none = __umul24((~(found | qsrc) >> (4 * q)) & 0xFu, 0x00204081u) & 0x01010101u;
+            const u32 src = __umul24((qsrc >> (4 * q)) & 0xFu, 0x00204081u) & 0x01010101u;
+            crow[q] = v | none * (u32)PAR_NONE | src * (u32)PAR_SRC;
         }
-        int code = t_sel < 0 ? PAR_NONE : (t_sel | (live ? 0 : 8));
-        code = d == DL_NONE ? PAR_NONE : code;
-        code = d == 0 ? PAR_SRC : code;
-        s_code[k] = (u8)code;
-        const int gi = r0 + r, gj = c0 + c;
-        if (out_dt && gi < H && gj < W)
-            out_dt[fo + (size_t)gi * W + gj] = d == DL_NONE ? 8192.0f : (float)d;  // float(INIT_DIST0 * 2^-16) == 8192.0f
     }
     __syncthreads();
     if (stop_after == 1) return;
-    u16 *s_ptr = s_big;  // the dl tile is dead
+    u16 *s_ptr = s_big;  // the planes are dead
     for (int k = tid; k < X_T * X_T; k += X_NT) {
         const int r = k >> 7, c = k & (X_T - 1);
-        const int code = s_code[k];
+        const int code = s_code[r * X_CP + c];
         int di, dj;
         tap_decode(code, di, dj);
         const u32 nr = (u32)(r + di), nc = (u32)(c + dj);
@@ -408,7 +491,7 @@ __global__ __launch_bounds__(X_NT) void k_exit(const u16 *__restrict__ dl, const
         const int gi = r0 + r, gj = c0 + c;
         if (gi >= H || gj >= W) continue;
         const int t = s_ptr[k] & 0x3FFF;  // terminal cell of k's in-tile chain
-        const int code = s_code[t];
+        const int code = s_code[(t >> 7) * X_CP + (t & (X_T - 1))];
         const int tr = r0 + (t >> 7), tc = c0 + (t & (X_T - 1));
         u32 e;
         if (code == PAR_SRC) {
