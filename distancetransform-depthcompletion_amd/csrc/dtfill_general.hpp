@@ -373,22 +373,35 @@ __global__ __launch_bounds__(X_NT) void k_exit(const u8 *__restrict__ planes, si
     u32 *s_pl = reinterpret_cast<u32 *>(s_big);  // [plane][row][X_RW]
     const bool has_src = finfo[b * FI_STRIDE + FI_NSRC] != 0;
 
-    // plane tile: rows r0-2 .. r0+129, image words c0/32 - 1 .. c0/32 + 4 (32-bit views of the byte / u64 arrays)
-    for (int k = tid; k < X_NPL * X_P * 6; k += X_NT) {
-        const int pl = k / (X_P * 6), rem = k - pl * (X_P * 6);
-        const int r = rem / 6, w = rem - r * 6;
-        const int gi = r0 + r - 2, wi = (c0 >> 5) - 1 + w;
-        u32 v = 0;
-        if (gi >= 0 && gi < H && wi >= 0 && wi * 32 < W) {
-            if (pl < 4)
-                v = reinterpret_cast<const u32 *>(planes + pl * plane_bytes + ((size_t)b * H + gi) * Wp)[wi];
-            else if (pl == 4)
-                v = reinterpret_cast<const u32 *>(srcbits + ((size_t)b * H + gi) * Wd)[wi];
+    // plane tile: rows r0-2 .. r0+129, image words c0/32 - 1 .. c0/32 + 4 (32-bit views of the byte / u64 arrays).
+    // All of a thread's loads are issued before its first LDS store (one memory round trip, not five).
+    {
+        constexpr int NITEM = X_NPL * X_P * 6, PER = (NITEM + X_NT - 1) / X_NT;
+        u32 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int k = tid + u * X_NT;
+            const int pl = k / (X_P * 6), rem = k - pl * (X_P * 6);
+            const int r = rem / 6, w = rem - r * 6;
+            const int gi = r0 + r - 2, wi = (c0 >> 5) - 1 + w;
+            const bool in = k < NITEM && gi >= 0 && gi < H && wi >= 0 && wi * 32 < W;
+            const int gic = min(max(gi, 0), H - 1), wic = min(max(wi, 0), Wd * 2 - 1);  // clamped: unconditional loads
+            const u32 *src = pl < 4 ? reinterpret_cast<const u32 *>(planes + min(pl, 3) * plane_bytes + ((size_t)b * H + gic) * Wp)
+                                    : reinterpret_cast<const u32 *>(srcbits + ((size_t)b * H + gic) * Wd);
+            const u32 ld = src[wic];
             const int up = min(W - wi * 32, 32);  // in-image columns of this word: [0, up)
-            const u32 inimg = up >= 32 ? 0xFFFFFFFFu : ((1u << up) - 1u);
-            v = pl == 5 ? inimg : (v & inimg);
+            const u32 inimg = !in ? 0u : (up >= 32 ? 0xFFFFFFFFu : ((1u << up) - 1u));
+            v[u] = pl == 5 ? inimg : (ld & inimg);
         }
-        s_pl[(pl * X_P + r) * X_RW + w] = v;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int k = tid + u * X_NT;
+            if (k < NITEM) {
+                const int pl = k / (X_P * 6), rem = k - pl * (X_P * 6);
+                const int r = rem / 6, w = rem - r * 6;
+                s_pl[(pl * X_P + r) * X_RW + w] = v[u];
+            }
+        }
     }
     __syncthreads();
     if (stop_after == 0) return;  // timing-only (DTFILL_EXIT_STOP)
