@@ -436,7 +436,8 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
                 }
                 // undecided pixels (not in D): no plane bit is set; give them F_NONE
                 const u32 und = mul_u24_opaque((~D[i] >> (4 * q)) & 0xFu, 0x00204081u) & 0x01010101u;
-                prow[i * 8 + q] = v | __umul24(und, (u32)F_NONE);
+                // (und has bit 24 set for the nibble's 4th pixel: NOT a 24-bit multiply)
+                prow[i * 8 + q] = v | und * (u32)F_NONE;
             }
         }
     }

@@ -34,6 +34,12 @@ for t in range(n):
               and np.array_equal(r["depth"].cpu().numpy()[st == 0], depth[st == 0], equal_nan=True))
         if not ok:
             bad += 1; print("MISMATCH case", t, path, (B, H, W), p, "labels differ:", int((r["index"].cpu().numpy() != lbl).sum()))
+            gi = r["index"].cpu().numpy(); gd = r["dt"].cpu().numpy()
+            print("   status", r["status"].cpu().numpy(), "dt differ:", int((gd != dt).sum()))
+            for bb, ii, jj in np.argwhere(gi != lbl)[:10]:
+                print("   frame", bb, "px", (ii, jj), "d", dt[bb, ii, jj], "got", gi[bb, ii, jj], "want", lbl[bb, ii, jj])
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.savez_compressed("gpurun_out/mismatch_%d_%s.npz" % (t, path), x=x, got=gi, want=lbl, dt=dt)
     if t % 5 == 0:
         d2, dt2, idx2, st2 = O.fill_batch(x, metric="l2")
         r = op2.run(xd); torch.cuda.synchronize()

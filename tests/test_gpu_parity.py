@@ -412,3 +412,25 @@ def test_shape_errors(gpu_op, pkg):
         gpu_op.run(torch.zeros((1, 5000, 5000), device="cuda:0"))
     with pytest.raises(ValueError):
         gpu_op.run(torch.zeros((5, 5), device="cuda:0"))
+
+
+def test_single_undecided_pixel_in_every_byte_lane(gpu_op, oracle):
+    """Exactly ONE pixel of the frame lies beyond a fused stage's halo (everything on and past an anti-diagonal
+    is a source, the corner pixel is R away from it), for the four positions the pixel can have inside the
+    4-pixel groups the kernel un-slices.  The stage must notice that single pixel and hand the frame on: a
+    lost "undecided" code in one byte lane once let it through with a garbage label (found by scripts/soak.py)."""
+    for R, widths, general in ((17, (157, 158, 159, 160), False), (33, (125, 126, 127, 128), True)):
+        for W in widths:
+            H = 40
+            i, j = np.mgrid[0:H, 0:W]
+            x = np.where(i + (W - 1 - j) >= R, 5.0 + 0.01 * ((i * 7 + j * 3) % 97), 0.0).astype(np.float32)[None]
+            depth, dt, lbl, status = oracle.fill_batch(x, 0.1, 0.1)
+            assert dt[0, 0, W - 1] == R and (dt[0] > R - 1).sum() == 1
+            got = run(gpu_op, x, path="auto")
+            assert np.array_equal(got["dt"], dt) and np.array_equal(got["index"], lbl), (R, W)
+            assert np.array_equal(got["depth"], depth) and bool(got["general"][0]) == general, (R, W)
+            # and mirrored: the top-left corner
+            xm = np.ascontiguousarray(x[:, :, ::-1])
+            depth, dt, lbl, status = oracle.fill_batch(xm, 0.1, 0.1)
+            got = run(gpu_op, xm, path="auto")
+            assert np.array_equal(got["dt"], dt) and np.array_equal(got["index"], lbl), (R, W, "mirrored")
