@@ -84,7 +84,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DTFILL_BENCH_FORCE_DIST"):  # the latter: exercise the RCCL path with one rank
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
