@@ -63,6 +63,33 @@ __device__ __forceinline__ void tap_step(const u32 (&src)[5], u32 (&taken)[F_HW]
     }
 }
 
+// one BACKWARD tap, evaluated after the level loop for all levels at once: the candidate r = q + (row, DJ) matches
+// iff it is decided and d(r) + WGT == d(q).  Only d mod 8 is kept (planes a0..a2 / b0..b2): d is an exact L1
+// distance field, so |d(r) - d(q)| <= WGT <= 3 and d(r) + WGT - d(q) lies in [0, 6]: zero iff zero mod 8.
+template <int DJ, int WGT, int ENC>
+__device__ __forceinline__ void bwd_tap(const u32 (&a0)[5], const u32 (&a1)[5], const u32 (&a2)[5], const u32 (&dv)[5],
+                                        const u32 (&b0)[F_HW], const u32 (&b1)[F_HW], const u32 (&b2)[F_HW],
+                                        u32 (&taken)[F_HW], u32 (&C)[6][F_HW]) {
+#pragma unroll
+    for (int i = 0; i < F_HW; ++i) {
+        const u32 x0 = hshift<DJ>(a0, i), x1 = hshift<DJ>(a1, i), x2 = hshift<DJ>(a2, i);
+        u32 s0, s1, s2;  // (d(r) + WGT) mod 8
+        if (WGT == 1) {
+            s0 = ~x0; s1 = x1 ^ x0; s2 = x2 ^ (x1 & x0);
+        } else if (WGT == 2) {
+            s0 = x0; s1 = ~x1; s2 = x2 ^ x1;
+        } else {
+            s0 = ~x0; s1 = ~(x1 ^ x0); s2 = x2 ^ (x1 | x0);
+        }
+        const u32 m = ~((s0 ^ b0[i]) | (s1 ^ b1[i]) | (s2 ^ b2[i])) & hshift<DJ>(dv, i);
+        const u32 sel = m & ~taken[i];
+        taken[i] |= m;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (ENC & (1 << j)) C[j][i] |= sel;
+    }
+}
+
 // 24-bit multiply the optimiser cannot see through: written as a plain product it folds the following shift
 // into the constant, which then no longer fits 24 bits and becomes a quarter-rate v_mul_lo_u32
 __device__ __forceinline__ u32 mul_u24_opaque(u32 a, u32 b) {
@@ -331,7 +358,10 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     __syncthreads();
     if (stop_after == 0) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
-    // ---- P1: levels
+    // ---- P1: levels.  Per level: E_t (dilation), L_t (forward taps, winners recorded), d mod 8 planes.
+    u32 P0[F_HW], P1[F_HW], P2[F_HW];  // bits 0..2 of the level at which a pixel was decided (sources: 0)
+#pragma unroll
+    for (int i = 0; i < F_HW; ++i) P0[i] = P1[i] = P2[i] = 0;
     for (int t = 1; t <= FR; ++t) {
         const int s1 = (t - 1) & 3, s2 = (t - 2) & 3, s3 = (t - 3) & 3, sw = t & 3;
         u32 nb[5], e1[5], l1[5], taken[F_HW], Et[F_HW], Lt[F_HW];
@@ -373,26 +403,16 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
         }
         ring_load5(s_ring, s1, 1, r + 2, wb, l1);  // L_{t-1}, this row
         tap_step<-1, ENC_F(7)>(l1, taken, C);
-#pragma unroll
-        for (int i = 0; i < F_HW; ++i) {
-            Lt[i] = taken[i] & Et[i];
-            taken[i] = ~(Et[i] & ~Lt[i]);  // backward chain only for the non-live pixels of E_t
-        }
-        // backward taps (negated offsets, same order); candidates are ALL pixels of levels t-3, t-2, t-1
-        ring_load5(s_ring, s3, 0, r + 4, wb, nb);  // E_{t-3}, row r+2
-        tap_step<1, 36 - ENC_F(0)>(nb, taken, C);
-        tap_step<-1, 36 - ENC_F(1)>(nb, taken, C);
         {
-            u32 e3[5], e2[5];
-            ring_load5(s_ring, s3, 0, r + 3, wb, e3);  // E_{t-3}, row r+1
-            ring_load5(s_ring, s2, 0, r + 3, wb, e2);  // E_{t-2}, row r+1
-            tap_step<2, 36 - ENC_F(2)>(e3, taken, C);
-            tap_step<1, 36 - ENC_F(3)>(e2, taken, C);
-            tap_step<0, 36 - ENC_F(4)>(e1d, taken, C);
-            tap_step<-1, 36 - ENC_F(5)>(e2, taken, C);
-            tap_step<-2, 36 - ENC_F(6)>(e3, taken, C);
+            const u32 m0 = (t & 1) ? 0xFFFFFFFFu : 0u, m1 = (t & 2) ? 0xFFFFFFFFu : 0u, m2 = (t & 4) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (int i = 0; i < F_HW; ++i) {
+                Lt[i] = taken[i] & Et[i];
+                P0[i] |= Et[i] & m0;
+                P1[i] |= Et[i] & m1;
+                P2[i] |= Et[i] & m2;
+            }
         }
-        tap_step<1, 36 - ENC_F(7)>(e1, taken, C);
 #pragma unroll
         for (int i = 0; i < F_HW; ++i) D[i] |= Et[i];
         ring_store3(s_ring, sw, 0, r + 2, wb, Et);
@@ -414,6 +434,41 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
             for (int w = 0; w < F_NT / 64; ++w) any |= s_any[t & 1][w];
             if (any != 3u) break;
         }
+    }
+    // ---- P1b: the backward taps of ALL levels in one pass (pixels that are decided but not live).  The d mod 8
+    // planes and D go through the ring's memory (slots 0 and 1; its guard rows and pad words are still zero).
+    __syncthreads();  // every wave is out of the level loop: the ring is dead
+    ring_store3(s_ring, 0, 0, r + 2, wb, P0);
+    ring_store3(s_ring, 0, 1, r + 2, wb, P1);
+    ring_store3(s_ring, 1, 0, r + 2, wb, P2);
+    ring_store3(s_ring, 1, 1, r + 2, wb, D);
+    __syncthreads();
+    {
+        u32 taken[F_HW], a0[5], a1[5], a2[5], dv[5];
+#pragma unroll
+        for (int i = 0; i < F_HW; ++i) {
+            // live = has a forward code or is a source (every forward enc and 18 are non-zero)
+            const u32 live = C[0][i] | C[1][i] | C[2][i] | C[3][i] | C[4][i] | C[5][i];
+            taken[i] = ~(D[i] & ~live);
+        }
+        auto row4 = [&](int row) {
+            ring_load5(s_ring, 0, 0, row, wb, a0);
+            ring_load5(s_ring, 0, 1, row, wb, a1);
+            ring_load5(s_ring, 1, 0, row, wb, a2);
+            ring_load5(s_ring, 1, 1, row, wb, dv);
+        };
+        // negated offsets of the cv2 taps, same order: (+2,+1) (+2,-1) (+1,+2) (+1,+1) (+1,0) (+1,-1) (+1,-2) (0,+1)
+        row4(r + 4);
+        bwd_tap<1, 3, 36 - ENC_F(0)>(a0, a1, a2, dv, P0, P1, P2, taken, C);
+        bwd_tap<-1, 3, 36 - ENC_F(1)>(a0, a1, a2, dv, P0, P1, P2, taken, C);
+        row4(r + 3);
+        bwd_tap<2, 3, 36 - ENC_F(2)>(a0, a1, a2, dv, P0, P1, P2, taken, C);
+        bwd_tap<1, 2, 36 - ENC_F(3)>(a0, a1, a2, dv, P0, P1, P2, taken, C);
+        bwd_tap<0, 1, 36 - ENC_F(4)>(a0, a1, a2, dv, P0, P1, P2, taken, C);
+        bwd_tap<-1, 2, 36 - ENC_F(5)>(a0, a1, a2, dv, P0, P1, P2, taken, C);
+        bwd_tap<-2, 3, 36 - ENC_F(6)>(a0, a1, a2, dv, P0, P1, P2, taken, C);
+        row4(r + 2);
+        bwd_tap<1, 1, 36 - ENC_F(7)>(a0, a1, a2, dv, P0, P1, P2, taken, C);
     }
     if (stop_after == 1) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
