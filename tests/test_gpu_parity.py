@@ -434,3 +434,23 @@ def test_single_undecided_pixel_in_every_byte_lane(gpu_op, oracle):
             depth, dt, lbl, status = oracle.fill_batch(xm, 0.1, 0.1)
             got = run(gpu_op, xm, path="auto")
             assert np.array_equal(got["dt"], dt) and np.array_equal(got["index"], lbl), (R, W, "mirrored")
+
+
+def test_input_pointer_alignment_does_not_matter(gpu_op, oracle):
+    """The 16-byte-load mask kernel is only used for 16-byte aligned frames with W % 4 == 0; a frame batch that
+    starts 4 bytes into an allocation takes the scalar-load kernel and must give the same maps."""
+    import torch
+
+    rng = np.random.default_rng(21)
+    B, H, W = 2, 96, 320
+    x = np.where(rng.random((B, H, W)) < 0.05, rng.uniform(1.0, 80.0, (B, H, W)), 0.0).astype(np.float32)
+    depth, dt, lbl, status = oracle.fill_batch(x, 0.1, 0.1)
+    flat = torch.zeros(B * H * W + 3, dtype=torch.float32, device="cuda:0")
+    for off in (0, 1, 2, 3):
+        view = flat[off:off + B * H * W].view(B, H, W)
+        view.copy_(torch.from_numpy(x))
+        assert view.data_ptr() % 16 == (flat.data_ptr() + 4 * off) % 16
+        res = gpu_op.run(view, 0.1, 0.1)
+        torch.cuda.synchronize()
+        assert np.array_equal(res["index"].cpu().numpy(), lbl) and np.array_equal(res["dt"].cpu().numpy(), dt), off
+        assert np.array_equal(res["depth"].cpu().numpy(), depth), off
