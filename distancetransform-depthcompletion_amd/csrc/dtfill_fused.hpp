@@ -112,12 +112,12 @@ __device__ __forceinline__ void ring_store3(u32 *__restrict__ ring, int slot, in
     for (int i = 0; i < F_HW; ++i) p[i] = w[i];
 }
 
-// P3 of the fused pass as a function of the staged window (s_par byte codes, s_rw rank words): tile
+// P3 of the fused pass as a function of the staged window (s_par byte codes, s_rw rank half words): tile
 // pixels walk to their sources in lock-step, d, rank -> label, gather, store.  Returns whether some tile pixel
 // was undecided.  NT = threads of the calling block.
 template <int FR, int NT>
 __device__ __forceinline__ bool fused_walk_epilogue(
-    const u8 *__restrict__ s_par, const short *__restrict__ s_tab, const uint4 *__restrict__ s_rw, int b, int H,
+    const u8 *__restrict__ s_par, const short *__restrict__ s_tab, const uint2 *__restrict__ s_rw, int b, int H,
     int W, int th, int tw, int r0, int c0, int wr0, int wc0, int sh, const float *__restrict__ x,
     const float *__restrict__ vlist,
     const int *__restrict__ finfo, float *__restrict__ out_depth, float *__restrict__ out_dt,
@@ -212,9 +212,8 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             // L1 distance to the nearest source IS d: |drow| + |dcol| of the two 16-bit halves in one instruction
             dd[e] = (int)__builtin_amdgcn_sad_u16((u32)pr_ << 16 | (u32)pc_, home[e], 0u);
             const int bitpos = sh + pc_;  // bit index in the row's image-aligned bit string, from word w0
-            const uint4 *rw = s_rw + pr_ * 4 + (bitpos >> 6);  // {bits lo, bits hi, rank before the word, -}
-            const u64 below = (1ull << (bitpos & 63)) - 1ull;  // one address, an 8-byte and a 4-byte read
-            lab[e] = (int)reinterpret_cast<const u32 *>(rw)[2] + __popcll(*reinterpret_cast<const u64 *>(rw) & below) + 1;
+            const uint2 rw = s_rw[pr_ * 8 + (bitpos >> 5)];  // {32 source bits, sources before them in the frame}
+            lab[e] = (int)rw.y + __popc(rw.x & ((1u << (bitpos & 31)) - 1u)) + 1;
             // depth_list[label-1] (tools.py:26).  A decided pixel has label >= 1, so the numpy wrap of
             // index -1 cannot occur here; an index past the value list is numpy's IndexError.
             const int idx = lab[e] - 1;
@@ -259,9 +258,9 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const long long h_nsrc = finfo[blockIdx.y * FI_STRIDE + FI_NSRC];
     const int h_dlb = finfo[blockIdx.y * FI_STRIDE + FI_DLB];
     __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
-    // per window row, the four image-aligned 64-pixel words it touches: {source bits lo, hi, sources before
-    // the word in frame raster order, -} -- one 16-byte LDS read per rank lookup
-    __shared__ uint4 s_rw[F_WHM * 4];
+    // per window row, the eight image-aligned 32-pixel half words it touches: {source bits, sources before them
+    // in frame raster order} -- one 8-byte LDS read and a 32-bit popcount per rank lookup
+    __shared__ uint2 s_rw[F_WHM * 8];
     __shared__ short s_tab[64];      // s_par displacement of the step enc (0 for the codes that are no step)
     __shared__ u32 s_any[2][F_NT / 64];  // per wave: did level t produce anything (double-buffered by level parity)
 
@@ -306,7 +305,8 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
             // if half 1 starts later), half 1 the rest
             const bool mine = hf == 0 ? kk < 2 : (kk >= 2 && kk < 4);
             if (mine) {
-                s_rw[r * 4 + kk] = make_uint4((u32)sb, (u32)(sb >> 32), rk, 0u);
+                s_rw[r * 8 + 2 * kk] = make_uint2((u32)sb, rk);
+                s_rw[r * 8 + 2 * kk + 1] = make_uint2((u32)(sb >> 32), rk + (u32)__popc((u32)sb));
             }
         }
         g[6] = 0;
