@@ -214,15 +214,19 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             const int bitpos = sh + pc_;  // bit index in the row's image-aligned bit string, from word w0
             const uint2 rw = s_rw[pr_ * 8 + (bitpos >> 5)];  // {32 source bits, sources before them in the frame}
             lab[e] = (int)rw.y + __popc(rw.x & ((1u << (bitpos & 31)) - 1u)) + 1;
-            // depth_list[label-1] (tools.py:26).  A decided pixel has label >= 1, so the numpy wrap of
-            // index -1 cannot occur here; an index past the value list is numpy's IndexError.
-            const int idx = lab[e] - 1;
-            const bool oob = idx >= nval;
-            bad |= ((ok >> e) & 1u) && oob;
-            // masks agree: the label-th value is x at the source.  The min only makes sure that a logic
-            // error could never become a wild global access (an LDS index out of range reads garbage at worst).
-            const u32 at_src = (u32)(src_base + __mul24(pr_, W) + pc_);
-            goff[e] = (oob ? 0u : min(misaligned ? (u32)idx : at_src, last_px)) << 2;  // byte offset
+            // depth_list[label-1] (tools.py:26).  A decided pixel has label >= 1, so the numpy wrap of index -1
+            // cannot occur here.  Masks agree (block-uniform): the label-th value is x at the source, and
+            // label <= nsrc = nval.  Masks differ: an index past the value list is numpy's IndexError.
+            // The min only makes sure that a logic error could never become a wild global access (an LDS index
+            // out of range reads garbage at worst).
+            if (!misaligned) {
+                goff[e] = min((u32)(src_base + __mul24(pr_, W) + pc_), last_px) << 2;  // byte offset
+            } else {
+                const int idx = lab[e] - 1;
+                const bool oob = idx >= nval;
+                bad |= ((ok >> e) & 1u) && oob;
+                goff[e] = (oob ? 0u : min((u32)idx, last_px)) << 2;
+            }
         }
         if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
         retire();  // the previous batch: its gathers had the whole walk above to arrive
