@@ -166,7 +166,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s,
-                               c.rowbase_v, c.finfo, c.vlist, c.fflag, c.fflag2, status, general_only ? 1 : 0);
+                               c.rowbase_v, c.finfo, c.vlist, c.fflag, c.fflag2, status, (general_only ? 1 : 0) | (fused_only ? 2 : 0));
     mark();
     if (!general_only) {
         // stage 1: halo 16 (tiles up to 96 x 160); stage 2, only for frames stage 1 flagged: halo 32
@@ -189,16 +189,16 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     }
     mark();
     if (!fused_only) {
-        k_colscan<false><<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, c.fflag2, H, W, Wd, (H + G_NCH - 1) / G_NCH, c.gu, c.g);
+        k_colscan<false><<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, c.fflag2, c.finfo, H, W, Wd, c.gu, c.g);
         mark();
         const int nU = W + 2 * (H - 1) + 1;
-        k_skew<<<dim3((nU + 63) / 64, B), 64 * G_NCH, 0, st>>>(c.gu, c.fflag2, H, W, c.dB);
+        k_skew<<<dim3((nU + 63) / 64, B), 64 * G_NCH, 0, st>>>(c.gu, c.fflag2, c.finfo, H, W, c.dB);
         mark();
         const int nseg = (W + 511) / 512;
         const size_t per_wave = (size_t)nseg * 512 * sizeof(int);  // <= 32 KiB at W = 8191
         const int wpb = (int)max((size_t)1, min((size_t)4, (size_t)65536 / per_wave));
-        k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag2, H, W, nseg,
-                                                                              Wd * 8, c.planes, c.plane_bytes, out_dt);
+        k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag2, c.finfo, H, W,
+                                                                              nseg, Wd * 8, c.planes, c.plane_bytes, out_dt);
         mark();
         {
             const int etx = (W + X_T - 1) / X_T, ety = (H + X_T - 1) / X_T;
@@ -232,9 +232,9 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
-                               c.finfo, c.vlist, c.fflag, c.fflag2, status, 0);
+                               c.finfo, c.vlist, c.fflag, c.fflag2, status, 2);
     mark();
-    k_colscan<true><<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, nullptr, H, W, Wd, (H + G_NCH - 1) / G_NCH, c.gu, c.g);
+    k_colscan<true><<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, nullptr, nullptr, H, W, Wd, c.gu, c.g);
     mark();
     k_l2row<<<dim3(H, B), 256, (size_t)W * sizeof(u16), st>>>(x, c.g, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W,
                                                          Wd, out_depth, out_dt, out_index, status);

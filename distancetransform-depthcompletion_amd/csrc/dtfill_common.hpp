@@ -12,7 +12,11 @@ constexpr int PAR_NONE = 0xFE;     // parent code: unreachable / undecided
 constexpr int MAX_HW_SUM = 8192;   // cv2's Q16 INIT_DIST0 = INT_MAX>>2 caps distances at 8191
 
 // frame facts written by k_frame: int32[FI_STRIDE] per frame
-constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_DLB = 3, FI_STRIDE = 4;  // DLB: lower bound of max d
+constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_DLB = 3;  // DLB: lower bound of max d (band mode: below the band)
+// Band mode (an empty band on top of an otherwise dense frame): the general kernels own rows [0, RW) and
+// compute on rows [0, HG) only, the fused stages own rows [RW, H).  Otherwise RW = HG = H.
+constexpr int FI_RW = 4, FI_HG = 5, FI_STRIDE = 8;
+constexpr int BAND_MARGIN = 65;  // HG = RW + 2 * 32 + 1: no source at or beyond that row can be nearest to (or tie for) a pixel above RW
 
 // cv2 tap order (OpenCV 3.4 distanceTransformEx_5x5), forward taps 0..7; backward tap t is the
 // NEGATED forward tap t with the same weight.  Parent code = t | (backward ? 8 : 0).

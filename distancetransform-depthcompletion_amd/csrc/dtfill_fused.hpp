@@ -118,7 +118,7 @@ __device__ __forceinline__ void ring_store3(u32 *__restrict__ ring, int slot, in
 template <int FR, int NT>
 __device__ __forceinline__ bool fused_walk_epilogue(
     const u8 *__restrict__ s_par, const short *__restrict__ s_tab, const uint2 *__restrict__ s_rw, int b, int H,
-    int W, int th, int tw, int r0, int c0, int wr0, int wc0, int sh, const float *__restrict__ x,
+    int W, int th, int tw, int r0, int c0, int wr0, int wc0, int sh, int rw_lo, const float *__restrict__ x,
     const float *__restrict__ vlist,
     const int *__restrict__ finfo, float *__restrict__ out_depth, float *__restrict__ out_dt,
     int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
@@ -174,7 +174,8 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             pos[e] = __mul24(FR + tr, F_P) + FR + tc;
             code[e] = s_par[pos[e]];
             ok |= (p < npx && code[e] != F_NONE) ? (1u << e) : 0u;
-            overflow |= p < npx && code[e] == F_NONE;  // undecidable here: the frame takes the general path
+            // undecidable here: the frame goes on to the next stage (band mode: rows above rw_lo are not ours)
+            overflow |= p < npx && code[e] == F_NONE && r0 + tr >= rw_lo;
         }
         // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
         // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
@@ -248,7 +249,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
 template <int FR>
 __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
-    const u32 *__restrict__ rowbase_s, const int *__restrict__ finfo, const float *__restrict__ vlist,
+    const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
     int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
     float *__restrict__ out_dt, int32_t *__restrict__ out_index, const int *__restrict__ gate,
     int *__restrict__ fflag, int *__restrict__ frame_status, int stop_after) {
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     // with the window loads below; the branch comes after those are in flight.)
     const long long h_nsrc = finfo[blockIdx.y * FI_STRIDE + FI_NSRC];
     const int h_dlb = finfo[blockIdx.y * FI_STRIDE + FI_DLB];
+    const int h_rw = finfo[blockIdx.y * FI_STRIDE + FI_RW];  // band mode (h_rw < H): rows above belong to the general kernels
     __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
     // per window row, the eight image-aligned 32-pixel half words it touches: {source bits, sources before them
     // in frame raster order} -- one 8-byte LDS read and a 32-bit popcount per rank lookup
@@ -273,6 +275,8 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * TH, c0 = tx * TW;
     const int th = min(TH, H - r0), tw = min(TW, W - c0);
+    const int rw_lo = h_rw < H ? h_rw : 0;  // first image row this stage is responsible for
+    if (r0 + th <= rw_lo) return;           // tile entirely above it (block-uniform)
     const int wr0 = r0 - FR, wc0 = c0 - FR;  // image coords of window cell (0,0)
     const int WH = th + 2 * FR, WW = tw + 2 * FR;
     const int ca = max(0, -wc0), cb = min(WW, W - wc0);  // in-image window columns [ca, cb)
@@ -330,14 +334,19 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
             // tile columns of window word wb + i: [FR, FR + tw) -- rows [FR, FR + th)
             const int tlo = max(FR - 32 * (wb + i), 0), tup = min(FR + tw - 32 * (wb + i), 32);
             u32 tm = 0;
-            if (r >= FR && r < FR + th && tup > tlo) tm = (tup >= 32 ? 0xFFFFFFFFu : ((1u << tup) - 1u)) & ~((1u << tlo) - 1u);
+            if (r >= FR && r < FR + th && r0 + r - FR >= rw_lo && tup > tlo) tm = (tup >= 32 ? 0xFFFFFFFFu : ((1u << tup) - 1u)) & ~((1u << tlo) - 1u);
             TM[i] = tm;
         }
     }
-    if (h_nsrc * (2 * FR * FR + 2 * FR + 1) < 14ll * H * W || h_dlb > FR) {  // block-uniform
-        if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (h_nsrc * (2 * FR * FR + 2 * FR + 1) < 14ll * (H - rw_lo) * W || h_dlb > FR) {  // block-uniform
+        // one writer per frame: the LAST tile (bottom right) -- in band mode the first tiles have returned above
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {
             fflag[blockIdx.y] = 1;
-            if (FR == 32) atomicOr(frame_status + blockIdx.y, DTFILL_FRAME_GENERAL_PATH);
+            if (FR == 32) {  // last fused stage: the WHOLE frame takes the general path (leaves band mode)
+                atomicOr(frame_status + blockIdx.y, DTFILL_FRAME_GENERAL_PATH);
+                finfo[blockIdx.y * FI_STRIDE + FI_RW] = H;
+                finfo[blockIdx.y * FI_STRIDE + FI_HG] = H;
+            }
         }
         return;
     }
@@ -503,10 +512,14 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     __syncthreads();
     if (stop_after == 2) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
-    const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_tab, s_rw, b, H, W, th, tw, r0, c0, wr0, wc0, sh, x, vlist,
+    const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_tab, s_rw, b, H, W, th, tw, r0, c0, wr0, wc0, sh, rw_lo, x, vlist,
                                                         finfo, out_depth, out_dt, out_index, frame_status);
     if (overflow) {
         fflag[b] = 1;  // same-value race
-        if (FR == 32) atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);  // last fused stage: general path next
+        if (FR == 32) {  // last fused stage: the WHOLE frame takes the general path next (leaves band mode)
+            atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);
+            finfo[b * FI_STRIDE + FI_RW] = H;
+            finfo[b * FI_STRIDE + FI_HG] = H;
+        }
     }
 }

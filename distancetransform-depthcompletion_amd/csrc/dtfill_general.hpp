@@ -16,17 +16,22 @@ constexpr int G_NCH = 16;  // row chunks (= waves per block) of the chunked colu
 // nearer than the one above: on a vertical tie the upper source has the smaller raster index).
 template <bool L2>
 __global__ __launch_bounds__(64 * G_NCH) void k_colscan(const u64 *__restrict__ srcbits,
-                                                        const int *__restrict__ fflag, int H, int W, int Wd,
-                                                        int CR, u16 *__restrict__ gu, u16 *__restrict__ g) {
+                                                        const int *__restrict__ fflag, const int *__restrict__ finfo,
+                                                        int Hfull, int W, int Wd, u16 *__restrict__ gu,
+                                                        u16 *__restrict__ g) {
     __shared__ int s_last[G_NCH][64], s_first[G_NCH][64];
     // ch is wave-uniform: as a scalar, the row loops and row addresses below run on the scalar unit
     const int b = blockIdx.y, wd = blockIdx.x, lane = threadIdx.x & 63, ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (fflag && !fflag[b]) return;
+    // rows [0, H) of the frame are scanned: all of them, or -- band mode -- the top part the general kernels own
+    // plus its margin (rows beyond count as source-free); the arrays keep the full-frame pitch
+    const int H = finfo ? finfo[b * FI_STRIDE + FI_HG] : Hfull;
+    const int CR = (H + G_NCH - 1) / G_NCH;
     const int j = wd * 64 + lane;
     const bool inb = j < W;
-    const size_t fo = (size_t)b * H * W;
+    const size_t fo = (size_t)b * Hfull * W;
     u16 *guf = gu + fo, *gf = g + fo;
-    const u64 *sbf = srcbits + (size_t)b * H * Wd + wd;
+    const u64 *sbf = srcbits + (size_t)b * Hfull * Wd + wd;
     const int i0 = min(ch * CR, H), i1 = min(i0 + CR, H);
 
     int last = -BIG, first = BIG;
@@ -138,15 +143,18 @@ __device__ __forceinline__ int skew_run(const u16 *__restrict__ guf, u16 *__rest
 }
 
 __global__ __launch_bounds__(64 * G_NCH) void k_skew(const u16 *__restrict__ gu, const int *__restrict__ fflag,
-                                                     int H, int W, u16 *__restrict__ dB) {
+                                                     const int *__restrict__ finfo, int Hfull, int W,
+                                                     u16 *__restrict__ dB) {
     __shared__ int s_end[G_NCH][64];
     const int b = blockIdx.y, lane = threadIdx.x & 63, ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar
     if (!fflag[b]) return;
+    const int H = finfo[b * FI_STRIDE + FI_HG];  // rows scanned (band mode: fewer than the frame has)
     const int nU = W + 2 * (H - 1) + 1;
     const int u0 = blockIdx.x * 64;
+    if (u0 >= nU) return;
     const int u = u0 + lane;
     const int u1 = min(u0 + 63, nU - 1);
-    const size_t fo = (size_t)b * H * W;
+    const size_t fo = (size_t)b * Hfull * W;
     const u16 *guf = gu + fo;
     u16 *dBf = dB + fo;
 
@@ -215,12 +223,14 @@ __device__ __forceinline__ void load8(const u16 *__restrict__ row, int idx0, int
 // planes + p * plane_bytes + (b * H + i) * Wp; Wp = bytes per row, a multiple of 8).
 __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, const u16 *__restrict__ gu,
                                                  const u16 *__restrict__ dB, const int *__restrict__ fflag,
-                                                 int H, int W, int nseg, int Wp, u8 *__restrict__ planes,
-                                                 size_t plane_bytes, float *__restrict__ out_dt) {
+                                                 const int *__restrict__ finfo, int H, int W, int nseg, int Wp,
+                                                 u8 *__restrict__ planes, size_t plane_bytes,
+                                                 float *__restrict__ out_dt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar row index
     const int i = blockIdx.x * (blockDim.x >> 6) + wave, b = blockIdx.y;
-    if (!fflag[b] || i >= H) return;  // wave-uniform; no block-level barrier below
+    if (!fflag[b] || i >= finfo[b * FI_STRIDE + FI_HG]) return;  // wave-uniform; no block-level barrier below
+    if (i >= finfo[b * FI_STRIDE + FI_RW]) out_dt = nullptr;    // band mode: the margin rows' distances are the fused stage's to write
     int *s_a = reinterpret_cast<int *>(smem) + (size_t)wave * nseg * 512;  // a | (dA == a) << 24, lane-private slots
     const size_t ro = ((size_t)b * H + i) * W;
     const u16 *grow = g + ro, *gurow = gu + ro, *dBrow = dB + ro;
@@ -359,7 +369,7 @@ __device__ __forceinline__ void exit_tap(const u32 (&a0)[3], const u32 (&a1)[3],
 
 __global__ __launch_bounds__(X_NT) void k_exit(const u8 *__restrict__ planes, size_t plane_bytes, int Wp,
                                               const u64 *__restrict__ srcbits, int Wd,
-                                              const int *__restrict__ finfo, const int *__restrict__ fflag, int H,
+                                              const int *__restrict__ finfo, const int *__restrict__ fflag, int Hfull,
                                               int W, int tiles_x, u32 *__restrict__ exitp, int stop_after) {
     __shared__ __attribute__((aligned(16))) u16 s_big[X_T * X_T];  // first the planes (22 KB), later the pointers
     __shared__ __attribute__((aligned(16))) u8 s_code[X_T * X_CP];
@@ -368,7 +378,9 @@ __global__ __launch_bounds__(X_NT) void k_exit(const u8 *__restrict__ planes, si
     if (!fflag[b]) return;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * X_T, c0 = tx * X_T;
-    const size_t fo = (size_t)b * H * W;
+    const int H = finfo[b * FI_STRIDE + FI_HG];  // rows that exist for this pass (band mode: fewer than the frame has)
+    if (r0 >= H) return;
+    const size_t fo = (size_t)b * Hfull * W;
     const int tid = threadIdx.x;
     u32 *s_pl = reinterpret_cast<u32 *>(s_big);  // [plane][row][X_RW]
     const bool has_src = finfo[b * FI_STRIDE + FI_NSRC] != 0;
@@ -386,8 +398,8 @@ __global__ __launch_bounds__(X_NT) void k_exit(const u8 *__restrict__ planes, si
             const int gi = r0 + r - 2, wi = (c0 >> 5) - 1 + w;
             const bool in = k < NITEM && gi >= 0 && gi < H && wi >= 0 && wi * 32 < W;
             const int gic = min(max(gi, 0), H - 1), wic = min(max(wi, 0), Wd * 2 - 1);  // clamped: unconditional loads
-            const u32 *src = pl < 4 ? reinterpret_cast<const u32 *>(planes + min(pl, 3) * plane_bytes + ((size_t)b * H + gic) * Wp)
-                                    : reinterpret_cast<const u32 *>(srcbits + ((size_t)b * H + gic) * Wd);
+            const u32 *src = pl < 4 ? reinterpret_cast<const u32 *>(planes + min(pl, 3) * plane_bytes + ((size_t)b * Hfull + gic) * Wp)
+                                    : reinterpret_cast<const u32 *>(srcbits + ((size_t)b * Hfull + gic) * Wd);
             const u32 ld = src[wic];
             const int up = min(W - wi * 32, 32);  // in-image columns of this word: [0, up)
             const u32 inimg = !in ? 0u : (up >= 32 ? 0xFFFFFFFFu : ((1u << up) - 1u));
@@ -531,7 +543,7 @@ __global__ __launch_bounds__(256) void k_final(
     if (!fflag[b]) return;
     const size_t fo = (size_t)b * H * W;
     const u32 *ef = exitp + fo;
-    const int N1 = H * W;
+    const int N1 = finfo[b * FI_STRIDE + FI_RW] * W;  // band mode: only the rows the general kernels own
     const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
     constexpr int FB = 8;  // pixels per lane whose loads are in flight together
     for (int pb = blockIdx.x * (256 * G_PPT) + threadIdx.x; pb < min(N1, (int)(blockIdx.x + 1) * 256 * G_PPT);
