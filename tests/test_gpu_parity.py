@@ -454,3 +454,35 @@ def test_input_pointer_alignment_does_not_matter(gpu_op, oracle):
         torch.cuda.synchronize()
         assert np.array_equal(res["index"].cpu().numpy(), lbl) and np.array_equal(res["dt"].cpu().numpy(), dt), off
         assert np.array_equal(res["depth"].cpu().numpy(), depth), off
+
+
+def test_band_mode_and_its_ways_out(gpu_op, oracle):
+    """An empty band on top of a dense frame: the general kernels own the band, the fused stages the rest (band
+    mode).  Variants: a hole below the band that stage 2 can still decide; a hole beyond both halos (the whole frame
+    must leave band mode); a band too tall for the margin to fit; bands at the bottom / in the middle (no band mode:
+    whole frame general); band + differing thresholds (value list gather)."""
+    rng = np.random.default_rng(77)
+    H, W = 352, 640
+
+    def dense(p=0.08):
+        return np.where(rng.random((H, W)) < p, rng.uniform(1.0, 80.0, (H, W)), 0.0).astype(np.float32)
+
+    frames = []
+    a = dense(); a[:100] = 0; frames.append(a)                                   # plain band mode
+    a = dense(); a[:60] = 0; a[200:240, 300:345] = 0; frames.append(a)           # + a hole with 16 < d <= 32: stage 2
+    a = dense(); a[:60] = 0; a[180:260, 250:340] = 0; frames.append(a)           # + a hole with d > 32: full general
+    a = dense(); a[:300] = 0; frames.append(a)                                   # band + margin does not fit: full general
+    a = dense(); a[250:] = 0; frames.append(a)                                   # band at the bottom
+    a = dense(); a[100:200] = 0; frames.append(a)                                # band in the middle
+    a = dense(); a[:40] = 0; frames.append(a)                                    # short bands
+    a = dense(); a[:33] = 0; frames.append(a)
+    a = dense(); a[:20] = 0; frames.append(a)                                    # 20 rows: the fused stage 2 decides it
+    x = np.stack(frames)
+    assert_equal_to_oracle(oracle, gpu_op, x)
+    got = run(gpu_op, x, path="auto")
+    assert got["general"][:7].all() and not got["general"][8]
+    # a band with thresholds that make the value list differ from the source list
+    assert_equal_to_oracle(oracle, gpu_op, x[:2], st=0.1, vt=30.0)
+    # one frame in band mode next to frames that are not
+    mix = np.stack([dense(), frames[0], dense(0.3)])
+    assert_equal_to_oracle(oracle, gpu_op, mix)
