@@ -25,6 +25,8 @@ for t in range(n):
         a, b_ = sorted(rng.integers(0, H + 1, 2)); x[:, a:b_] *= (rng.random((B, 1, 1)) < 0.5)
     if rng.random() < 0.3:
         a, b_ = sorted(rng.integers(0, W + 1, 2)); x[:, :, a:b_] = 0
+    if rng.random() < 0.3 and H > 120:  # LiDAR sky: an empty band on top (band mode and its ways out)
+        x[:, :int(rng.integers(20, H - 40))] *= (rng.random((B, 1, 1)) < 0.7)
     depth, dt, lbl, st = O.fill_batch(x)
     xd = torch.from_numpy(x).cuda()
     for path in ("auto", "general"):
