@@ -3,23 +3,27 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------------
-// k_fused: one workgroup (2 waves) per window = tile (<= 96 x 160) + halo FR, bit-sliced.
+// k_fused: one workgroup (4 waves) per window = tile (<= 96 x 160) + halo FR, bit-sliced.
 //
-// Lane r owns window row r as six 32-bit words per bit plane (bit c%32 of word c/32 = window column c).
-// Level-synchronous form of the identity in the file header (checked in
-// tests/parallel_model.py): with E_t = {d == t} and L_t = live pixels of E_t (E_0 = L_0 = sources),
+// Lane (r, half) owns half of window row r as three 32-bit words per bit plane (bit c%32 of word c/32 = window
+// column c).  Level-synchronous form of the identity of DESIGN.md section 2 (checked in tests/parallel_model.py):
+// with E_t = {d == t} and L_t = live pixels of E_t (E_0 = L_0 = sources),
 //   E_t = dilate4(D_{t-1}) & ~D_{t-1} & in-image
 //   forward tap T = (di,dj,w) offers   shift(L_{t-w}, di, dj)   to the pixels of E_t; L_t = those offered any
-//   backward tap (negated offset)      shift(E_{t-w}, -di, -dj) to E_t \ L_t
+//   backward tap (negated offset)      candidates of level t-w for the pixels of E_t \ L_t
 //   the FIRST tap in cv2 order wins (taken-mask chain); the winning step is recorded in six "code planes"
 //   holding the bits of enc = (di+2)<<3 | (dj+2)  (sources: enc 18 = step (0,0)).
-// A horizontal shift of a row is one v_alignbit per word; rows r-2..r+2 of the previous three levels
-// come from a 4-slot LDS ring (one barrier per level).  Levels stop at FR or when a level is empty.
+// The level loop runs the forward taps (they define L_t) and ORs E_t into three planes of d mod 8; the backward
+// taps run ONCE after it for all levels, on those planes (bwd_tap).  A horizontal shift of a row is one
+// v_alignbit per word; rows r-2..r+2 of the previous three levels come from a 4-slot LDS ring (one barrier per
+// level).  Levels stop at FR, when a level is empty, or when every tile pixel is decided.
 // Then every lane un-slices its row, 4 pixels per step, into the byte array s_par (2 * enc; F_NONE =
 // undecided), which reuses the ring's memory, and the tile pixels walk to their sources in lock-step:
 // the byte is the byte offset of the step's s_par displacement in a 64-entry int16 table (s_tab), so a
 // hop is two LDS reads and one add; d is |drow| + |dcol| to the root.
-// LDS: 28.9 KB ring/s_par + 6 KB bit words and ranks.
+// Band mode (finfo FI_RW < H): rows above FI_RW belong to the general kernels -- tiles entirely above are skipped,
+// undecided pixels above are not reported.
+// LDS: 28.9 KB ring/s_par + 8 KB rank records.
 // ------------------------------------------------------------------------------------------------
 constexpr int F_WHM = 128;  // window rows
 constexpr int F_WWM = 192;  // window columns = 6 words
