@@ -184,12 +184,13 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     const bool force_general = mode & 1;  // every frame takes the general kernels (tests)
     const bool no_band = mode & 2;        // the general kernels will not run at all (tests; the l2 pass): no band mode
     __shared__ u32 s_ws[4], s_wv[4];
-    __shared__ int s_mis, s_dlb, s_k0;
+    __shared__ int s_mis, s_dlb, s_k0, s_rest;  // s_k0: end row of the band (0: none)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 *cs_ = rowcnt_s + (size_t)b * H, *cv_ = rowcnt_v + (size_t)b * H;
     if (tid == 0) {
         s_dlb = 0;
-        s_k0 = H;
+        s_k0 = 0;
+        s_rest = 0;
     }
     u32 *bs_ = rowbase_s + (size_t)b * H, *bv_ = rowbase_v + (size_t)b * H;
     if (tid == 0) s_mis = 0;
@@ -250,42 +251,51 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
             if (cs_[i] == 0) atomicOr(&s_empty[i >> 5], 1u << (i & 31));
         __syncthreads();
         auto empty = [&](int i) { return (s_empty[i >> 5] >> (i & 31)) & 1u; };
-        // leading run of source-free rows (the "sky" of a LiDAR frame): its length k0 (H if there is no source)
-        {   // first row with a source: one candidate per 32-row word of the bitmap (H <= 8191: at most 256 words)
-            const int i0 = tid * 32;
-            const u32 rows_here = i0 < H ? (H - i0 >= 32 ? 0xFFFFFFFFu : ((1u << (H - i0)) - 1u)) : 0u;
-            const u32 occupied = ~s_empty[tid] & rows_here;
-            if (occupied) atomicMin(&s_k0, i0 + __ffs((int)occupied) - 1);
-        }
-        __syncthreads();
-        const int k0 = s_k0;
-        // band mode: only that leading run is beyond the fused halos -- the bound below then ignores it
-        const bool band_candidate = !force_general && !no_band && k0 > 32 && k0 + BAND_MARGIN < H;
-        int dlb = 0;
-        for (int i = tid; i < H; i += 256) {
-            if (!empty(i) || (i + 1 < H && empty(i + 1))) continue;  // not the last row of a run
+        // Per run of source-free rows (each thread looks at the runs ENDING at its rows): the distance it forces.
+        // s_dlb = the largest one; s_rbad = end of the last run that is beyond both fused halos and does not touch
+        // the bottom edge -- everything above that row is the band of "band mode" (the sky of a LiDAR frame, with
+        // or without stray points in it).
+        auto forced = [&](int i, int &start) {  // run ending at row i (caller checked that it ends there)
             int k = 1;
             while (i - k >= 0 && empty(i - k)) ++k;
-            if (band_candidate && i - k < 0) continue;  // the leading run itself
-            const bool edge = (i - k < 0) || (i + 1 >= H);
-            dlb = max(dlb, (i - k < 0 && i + 1 >= H) ? BIG : edge ? k : (k + 1) / 2);
+            start = i - k + 1;
+            const bool top = start == 0, bottom = i + 1 >= H;
+            return (top && bottom) ? BIG : (top || bottom) ? k : (k + 1) / 2;
+        };
+        int dlb = 0, rbad = 0;
+        for (int i = tid; i < H; i += 256) {
+            if (!empty(i) || (i + 1 < H && empty(i + 1))) continue;  // not the last row of a run
+            int start;
+            const int f = forced(i, start);
+            dlb = max(dlb, f);
+            if (f > 32 && i + 1 < H) rbad = i + 1;
         }
         if (dlb) atomicMax(&s_dlb, dlb);
+        if (rbad) atomicMax(&s_k0, rbad);
+        __syncthreads();
+        // what the rows below the band still force
+        const int Rb = s_k0;
+        if (Rb > 0 && Rb + BAND_MARGIN < H) {  // block-uniform
+            int rest = 0;
+            for (int i = tid; i < H; i += 256) {
+                if (i < Rb || !empty(i) || (i + 1 < H && empty(i + 1))) continue;
+                int start;
+                rest = max(rest, forced(i, start));
+            }
+            if (rest) atomicMax(&s_rest, rest);
+        }
     }
     __syncthreads();
     const int misaligned = s_mis;
     if (tid == 0) {
-        const int k0 = s_k0;
-        const bool band_candidate = !force_general && !no_band && k0 > 32 && k0 + BAND_MARGIN < H;
-        const bool band = band_candidate && s_dlb <= 32;
-        // not band mode after all: the leading run counts (edge run: d >= k0)
-        const int dlb = (band_candidate && !band) ? max(s_dlb, k0) : s_dlb;
-        finfo[b * FI_STRIDE + FI_RW] = band ? k0 : H;
-        finfo[b * FI_STRIDE + FI_HG] = band ? k0 + BAND_MARGIN : H;
+        const int Rb = s_k0;
+        const bool band = !force_general && !no_band && Rb > 0 && Rb + BAND_MARGIN < H && s_rest <= 32;
+        finfo[b * FI_STRIDE + FI_RW] = band ? Rb : H;
+        finfo[b * FI_STRIDE + FI_HG] = band ? Rb + BAND_MARGIN : H;
         finfo[b * FI_STRIDE + FI_NSRC] = (int)run_s;
         finfo[b * FI_STRIDE + FI_NVAL] = (int)run_v;
         finfo[b * FI_STRIDE + FI_MISALIGNED] = misaligned;
-        finfo[b * FI_STRIDE + FI_DLB] = dlb;
+        finfo[b * FI_STRIDE + FI_DLB] = band ? s_rest : s_dlb;
         fflag[b] = 0;                       // set by k_fused<16>: the frame needs a wider halo
         const bool general = force_general || band;  // band mode: rows [0, RW) take the general kernels
         fflag2[b] = general ? 1 : 0;  // also set by k_fused<32>: the whole frame needs the general path

@@ -486,3 +486,20 @@ def test_band_mode_and_its_ways_out(gpu_op, oracle):
     # one frame in band mode next to frames that are not
     mix = np.stack([dense(), frames[0], dense(0.3)])
     assert_equal_to_oracle(oracle, gpu_op, mix)
+
+
+def test_band_mode_with_stray_points_in_the_sky(gpu_op, oracle):
+    """The band need not be perfectly empty: a few sources inside it split the leading run, the band then ends
+    with the last run of empty rows that is beyond the fused halos."""
+    rng = np.random.default_rng(78)
+    H, W = 352, 640
+    frames = []
+    for stray in (1, 3, 10):
+        a = np.where(rng.random((H, W)) < 0.08, rng.uniform(1.0, 80.0, (H, W)), 0.0).astype(np.float32)
+        a[:120] = 0
+        for _ in range(stray):
+            a[rng.integers(0, 115), rng.integers(0, W)] = 7.5
+        frames.append(a)
+    x = np.stack(frames)
+    assert_equal_to_oracle(oracle, gpu_op, x)
+    assert run(gpu_op, x, path="auto")["general"].all()
