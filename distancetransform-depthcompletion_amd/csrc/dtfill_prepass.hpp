@@ -243,32 +243,55 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     // empty rows forces d >= ceil(k/2) in its middle row, d >= k at the border row if it touches the top or
     // bottom edge.  Each thread looks at the run ENDING at its rows (cheap: the counts are in L2).
     {
-        // "row has no source" as bits in LDS (H <= 8191 -> 256 words), so walking a run costs LDS reads only
-        __shared__ u32 s_empty[256];
+        // "row has no source" as bits in LDS (H <= 8191 -> 256 words), and "sky row": fewer than one source per 64
+        // columns within the 33 rows around it (from the row prefix sums this block has just written) -- what the
+        // band detection looks at; a frame that is thin everywhere but evenly so has no sky rows
+        __shared__ u32 s_empty[256], s_sparse[256];
         s_empty[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < H; i += 256)
+        s_sparse[tid] = 0;
+        __syncthreads();  // also makes this block's bs_ stores visible to its own loads below
+        for (int i = tid; i < H; i += 256) {
             if (cs_[i] == 0) atomicOr(&s_empty[i >> 5], 1u << (i & 31));
+            const int lo = max(i - 16, 0), hi = min(i + 17, H);
+            const u32 around = (hi < H ? bs_[hi] : run_s) - bs_[lo];
+            if (around * 64u < (u32)W) atomicOr(&s_sparse[i >> 5], 1u << (i & 31));
+        }
         __syncthreads();
         auto empty = [&](int i) { return (s_empty[i >> 5] >> (i & 31)) & 1u; };
-        // Per run of source-free rows (each thread looks at the runs ENDING at its rows): the distance it forces.
-        // s_dlb = the largest one; s_rbad = end of the last run that is beyond both fused halos and does not touch
-        // the bottom edge -- everything above that row is the band of "band mode" (the sky of a LiDAR frame, with
-        // or without stray points in it).
+        auto sparse = [&](int i) { return (s_sparse[i >> 5] >> (i & 31)) & 1u; };
+        // first row of the run of set bits that ends at row i (bit i is set): whole words at a time
+        auto run_start = [&](const u32 *bm, int i) {
+            int w = i >> 5;
+            const u32 zeros_below = ~bm[w] & ((2u << (i & 31)) - 1u);  // cleared bits at or below bit i of this word
+            if (zeros_below) return w * 32 + 32 - __clz((int)zeros_below);
+            while (w > 0 && bm[w - 1] == 0xFFFFFFFFu) --w;
+            if (w == 0) return 0;
+            return (w - 1) * 32 + 32 - __clz((int)~bm[w - 1]);
+        };
+        // Per run of source-free rows (each thread looks at the runs ENDING at its rows): the distance it forces;
+        // s_dlb = the largest one (a true lower bound of the frame's largest distance).
+        // Band detection (a guess, never a correctness condition): s_k0 = end of the last run of SKY rows that
+        // would be beyond both fused halos if it were empty and does not touch the bottom edge -- everything above
+        // that row is the band of "band mode" (the sky of a LiDAR frame, with or without stray points in it).
         auto forced = [&](int i, int &start) {  // run ending at row i (caller checked that it ends there)
-            int k = 1;
-            while (i - k >= 0 && empty(i - k)) ++k;
-            start = i - k + 1;
+            start = run_start(s_empty, i);
+            const int k = i - start + 1;
             const bool top = start == 0, bottom = i + 1 >= H;
             return (top && bottom) ? BIG : (top || bottom) ? k : (k + 1) / 2;
         };
         int dlb = 0, rbad = 0;
         for (int i = tid; i < H; i += 256) {
+            if (sparse(i) && i + 1 < H && !sparse(i + 1)) {  // last row of a run of sky rows, not at the bottom
+                const int st = run_start(s_sparse, i), k = i - st + 1;
+                if ((st == 0 ? k : (k + 1) / 2) > 32) {  // same bound, as if those rows were empty
+                    int e = i + 1;  // the last rows of the sky see the sources below it in their window: take the
+                    while (e < H && empty(e)) ++e;  // source-free rows that follow (at most 16) into the band
+                    if (e < H) rbad = e;
+                }
+            }
             if (!empty(i) || (i + 1 < H && empty(i + 1))) continue;  // not the last row of a run
             int start;
-            const int f = forced(i, start);
-            dlb = max(dlb, f);
-            if (f > 32 && i + 1 < H) rbad = i + 1;
+            dlb = max(dlb, forced(i, start));
         }
         if (dlb) atomicMax(&s_dlb, dlb);
         if (rbad) atomicMax(&s_k0, rbad);
