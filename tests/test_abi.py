@@ -47,6 +47,21 @@ def test_argument_errors_without_gpu(pkg):
     assert L.dtfill_batch(256, 1, 8, 8, 0.1, 0.1, 7, 256, None, None, None, 256, 1 << 20, None) == -4
     assert L.dtfill_batch(256, 1, 8, 8, 0.1, 0.1, 0, 256, None, None, None, 256, 16, None) == -3  # too small
     assert L.dtfill_batch(256, 1, 8, 8, 0.1, 0.1, 0, 256, None, None, None, 260, 1 << 20, None) == -3  # unaligned
+    # the entry points of the callers' steps either side of the path
+    assert L.dtfill_outlier_removal(None, 1, 8, 8, None, None) == -1
+    assert L.dtfill_outlier_removal(256, 1, 3, 8, 256, None) == -2  # reflect-101 over a 7x7 window needs >= 4 rows
+    assert L.dtfill_generate_multi_channel(None, None, 1, 8, 8, 7, 4, None, None, None, None) == -1
+    assert L.dtfill_generate_multi_channel(256, 256, 1, 8, 8, 6, 4, 256, 256, 256, None) == -2  # even table
+    assert L.dtfill_crop_floor(None, 1, 8, 8, 0, 8, 0, 8, 0, 0.0, None, None) == -1
+    assert L.dtfill_crop_floor(256, 1, 8, 8, 4, 4, 0, 8, 0, 0.0, 256, None) == -2  # empty crop
+    assert L.dtfill_crop_floor(256, 1, 8, 8, 0, 9, 0, 8, 0, 0.0, 256, None) == -2  # crop outside the frame
+    assert L.dtfill_png16(None, 1, 8, 8, 96, 1, 0.9, 0.0, 100.0, 256.0, None, None) == -1
+    assert L.dtfill_png16(256, 1, 8, 8, -1, 1, 0.9, 0.0, 100.0, 256.0, 256, None) == -2
+    assert L.dtfill_metrics_workspace_bytes(0) == 0 and L.dtfill_metrics_workspace_bytes(4) > 0
+    assert L.dtfill_metrics(None, None, 1, 64, 0, None, None, 0, None) == -1
+    assert L.dtfill_metrics(256, 256, 1, 0, 0, 256, 256, 1 << 20, None) == -2
+    assert L.dtfill_metrics(256, 256, 1, 64, 5, 256, 256, 1 << 20, None) == -4
+    assert L.dtfill_metrics(256, 256, 4, 64, 0, 256, 256, 16, None) == -3
 
 
 def test_product_does_not_import_oracle():
