@@ -216,7 +216,7 @@ int oracle_fill_frame_l2(const float *x, int H, int W, float src_thr, float val_
                          float *out_depth, float *out_dt, int32_t *out_idx)
 {
     size_t n = (size_t)H * W, p, nval = 0;
-    uint8_t *mask = (uint8_t *)malloc(n);
+    uint8_t *mask = (uint8_t *)calloc(n ? n : 1, 1);
     int32_t *d2 = (int32_t *)malloc(n * sizeof(int32_t));
     int32_t *near = (int32_t *)malloc(n * sizeof(int32_t));
     int32_t *rank = (int32_t *)malloc(n * sizeof(int32_t));
