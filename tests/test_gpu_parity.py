@@ -486,6 +486,13 @@ def test_band_mode_and_its_ways_out(gpu_op, oracle):
     # one frame in band mode next to frames that are not
     mix = np.stack([dense(), frames[0], dense(0.3)])
     assert_equal_to_oracle(oracle, gpu_op, mix)
+    # optional outputs in band mode: each map is written by two kernel families (rows above / below the band)
+    depth, dt, lbl, status = oracle.fill_batch(mix, 0.1, 0.1)
+    for want in (("index",), ("dt",), ("depth",), ("depth", "dt")):
+        got = run(gpu_op, mix, want=want)
+        for k, ref in (("index", lbl), ("dt", dt), ("depth", depth)):
+            if k in want:
+                assert np.array_equal(got[k], ref), (want, k)
 
 
 def test_band_mode_with_stray_points_in_the_sky(gpu_op, oracle):
