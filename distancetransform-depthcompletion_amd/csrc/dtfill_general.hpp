@@ -35,10 +35,29 @@ __global__ __launch_bounds__(64 * G_NCH) void k_colscan(const u64 *__restrict__ 
     const int i0 = min(ch * CR, H), i1 = min(i0 + CR, H);
 
     int last = -BIG, first = BIG;
-    for (int i = i0; i < i1; ++i) {
-        const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
-        last = s ? i : last;
-        first = s ? min(first, i) : first;
+    u32 bits = 0;  // fast path: the chunk's source bits of this lane's column
+    if (CR <= 32) {
+        // all of the chunk's words at once (wave-uniform addresses: 32 scalar loads in flight instead of one
+        // load-and-wait per row)
+#pragma unroll
+        for (int kb = 0; kb < 32; kb += 16) {  // two batches of 16: 32 words at once would cost a block per CU in SGPRs
+            u64 w[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) w[k] = sbf[(size_t)min(i0 + kb + k, max(i1 - 1, 0)) * Wd];
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (i0 + kb + k < i1) bits |= (u32)((w[k] >> lane) & 1ull) << (kb + k);
+        }
+        if (bits) {
+            last = i0 + 31 - __clz((int)bits);
+            first = i0 + __ffs((int)bits) - 1;
+        }
+    } else {
+        for (int i = i0; i < i1; ++i) {
+            const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
+            last = s ? i : last;
+            first = s ? min(first, i) : first;
+        }
     }
     s_last[ch][lane] = last;
     s_first[ch][lane] = first;
@@ -54,8 +73,6 @@ __global__ __launch_bounds__(64 * G_NCH) void k_colscan(const u64 *__restrict__ 
     if (CR <= 32) {
         // fast path (H <= 512): the chunk's source bits sit in one register, the from-below distances of its
         // rows in (statically indexed) registers; one store pass, nothing is re-read
-        u32 bits = 0;
-        for (int i = i0; i < i1; ++i) bits |= (u32)((sbf[(size_t)i * Wd] >> lane) & 1ull) << (i - i0);
         const int n = i1 - i0;
         int dnv[32];
 #pragma unroll
