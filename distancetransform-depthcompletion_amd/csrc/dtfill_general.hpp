@@ -235,6 +235,18 @@ __device__ __forceinline__ void load8(const u16 *__restrict__ row, int idx0, int
     for (int q = 0; q < 8; ++q) v[q] = v[q] == INF16 ? BIG : v[q];
 }
 
+// the same 8 values as one raw 16-byte load (rows 16-byte aligned, W % 8 == 0: a lane's 8 pixels are inside the row
+// or outside together) -- kept raw so that the NEXT segment's load can be in flight while this one is worked on
+__device__ __forceinline__ uint4 load8_raw(const u16 *__restrict__ row, int idx0, int W) {
+    return idx0 < W ? *reinterpret_cast<const uint4 *>(row + idx0) : make_uint4(~0u, ~0u, ~0u, ~0u);
+}
+__device__ __forceinline__ void unpack8(const uint4 q, int (&v)[8]) {
+    v[0] = q.x & 0xFFFF; v[1] = q.x >> 16; v[2] = q.y & 0xFFFF; v[3] = q.y >> 16;
+    v[4] = q.z & 0xFFFF; v[5] = q.z >> 16; v[6] = q.w & 0xFFFF; v[7] = q.w >> 16;
+#pragma unroll
+    for (int q2 = 0; q2 < 8; ++q2) v[q2] = v[q2] == INF16 ? BIG : v[q2];
+}
+
 // Output: the float distance map (the last consumer of the full d) and four bit planes for k_exit, one byte
 // per 8 pixels and plane: d & 1, d >> 1 & 1, d >> 2 & 1, live (plane p of row i starts at
 // planes + p * plane_bytes + (b * H + i) * Wp; Wp = bytes per row, a multiple of 8).
@@ -254,11 +266,26 @@ __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, cons
     const bool vec = (W & 7) == 0;  // rows start 16-byte aligned (the arrays are 256-byte aligned)
 
     int carry_a = BIG, carry_dA = BIG;  // min of (value - index) over everything left of the segment
+    uint4 rg = make_uint4(0, 0, 0, 0), ru = rg;  // prefetched raw segment (vec rows only)
+    if (vec) {
+        rg = load8_raw(grow, lane * 8, W);
+        ru = load8_raw(gurow, lane * 8, W);
+    }
     for (int sg = 0; sg < nseg; ++sg) {
         const int idx0 = sg * 512 + lane * 8;
         int gv[8], uv[8];
-        load8(grow, idx0, W, vec, gv);
-        load8(gurow, idx0, W, vec, uv);
+        if (vec) {
+            const uint4 cg = rg, cu = ru;
+            if (sg + 1 < nseg) {  // next segment's loads fly during this segment's scans
+                rg = load8_raw(grow, idx0 + 512, W);
+                ru = load8_raw(gurow, idx0 + 512, W);
+            }
+            unpack8(cg, gv);
+            unpack8(cu, uv);
+        } else {
+            load8(grow, idx0, W, vec, gv);
+            load8(gurow, idx0, W, vec, uv);
+        }
         int ma = BIG, md = BIG, la[8], ld[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -279,6 +306,8 @@ __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, cons
         carry_dA = __shfl(min(md, ed), 63);
     }
     int carry_b = BIG;  // min of (a + index) over everything right of the segment
+    uint4 rb = make_uint4(0, 0, 0, 0);
+    if (vec) rb = load8_raw(dBrow, (nseg - 1) * 512 + lane * 8, W);
     for (int sg = nseg - 1; sg >= 0; --sg) {
         const int idx0 = sg * 512 + lane * 8;
         int av[8], fl[8], ms = BIG, ls[8];
@@ -292,7 +321,13 @@ __global__ __launch_bounds__(256) void k_rowscan(const u16 *__restrict__ g, cons
         }
         const int es = min(wave_excl_suffix_min(ms, lane), carry_b);
         int dbv[8];
-        load8(dBrow, idx0, W, vec, dbv);
+        if (vec) {
+            const uint4 cb = rb;
+            if (sg > 0) rb = load8_raw(dBrow, idx0 - 512, W);
+            unpack8(cb, dbv);
+        } else {
+            load8(dBrow, idx0, W, vec, dbv);
+        }
         u32 p0 = 0, p1 = 0, p2 = 0, pl = 0;
         float fd[8];
 #pragma unroll
