@@ -53,10 +53,16 @@ __global__ __launch_bounds__(64 * G_NCH) void k_colscan(const u64 *__restrict__ 
             first = i0 + __ffs((int)bits) - 1;
         }
     } else {
-        for (int i = i0; i < i1; ++i) {
-            const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
-            last = s ? i : last;
-            first = s ? min(first, i) : first;
+        for (int ib = i0; ib < i1; ib += 16) {  // 16 rows' words per round trip (wave-uniform addresses: scalar loads)
+            u64 w[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) w[k] = sbf[(size_t)min(ib + k, i1 - 1) * Wd];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bool s = ib + k < i1 && ((w[k] >> lane) & 1ull);
+                last = s ? ib + k : last;
+                first = s ? min(first, ib + k) : first;
+            }
         }
     }
     s_last[ch][lane] = last;
@@ -98,23 +104,44 @@ __global__ __launch_bounds__(64 * G_NCH) void k_colscan(const u64 *__restrict__ 
         }
         return;
     }
-#pragma unroll 4
-    for (int i = i0; i < i1; ++i) {
-        const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
-        up = s ? 0 : min(up + 1, BIG);
-        if (inb) guf[(size_t)i * W + j] = st16(up);
+    // any chunk height: the same two sweeps, 16 rows' words and (up sweep) 16 rows' gu values per round trip
+    for (int ib = i0; ib < i1; ib += 16) {
+        u64 w[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = sbf[(size_t)min(ib + k, i1 - 1) * Wd];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = ib + k;
+            if (i < i1) {  // wave-uniform
+                const bool s = (w[k] >> lane) & 1ull;
+                up = s ? 0 : min(up + 1, BIG);
+                if (inb) guf[(size_t)i * W + j] = st16(up);
+            }
+        }
     }
-#pragma unroll 4
-    for (int i = i1 - 1; i >= i0; --i) {
-        const bool s = (sbf[(size_t)i * Wd] >> lane) & 1ull;
-        dn = s ? 0 : min(dn + 1, BIG);
-        if (inb) {
-            const int u = ld16(guf + (size_t)i * W + j);
-            if (L2) {
-                const int m = min(u, dn);
-                gf[(size_t)i * W + j] = m >= 0x7FFF ? (u16)INF16 : (u16)(m | (dn < u ? 0x8000 : 0));
-            } else {
-                gf[(size_t)i * W + j] = st16(min(u, dn));
+    for (int it = i1; it > i0; it -= 16) {  // rows it-1 down to it-16
+        u64 w[16];
+        int uu[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = max(it - 1 - k, i0);
+            w[k] = sbf[(size_t)i * Wd];
+            uu[k] = inb ? ld16(guf + (size_t)i * W + j) : BIG;  // this lane's own stores of the down sweep
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = it - 1 - k;
+            if (i < i0) continue;  // wave-uniform
+            const bool s = (w[k] >> lane) & 1ull;
+            dn = s ? 0 : min(dn + 1, BIG);
+            if (inb) {
+                const int u = uu[k];
+                if (L2) {
+                    const int m = min(u, dn);
+                    gf[(size_t)i * W + j] = m >= 0x7FFF ? (u16)INF16 : (u16)(m | (dn < u ? 0x8000 : 0));
+                } else {
+                    gf[(size_t)i * W + j] = st16(min(u, dn));
+                }
             }
         }
     }
