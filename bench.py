@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
     ap.add_argument("--workload", default="kitti_b32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--path", default="auto", choices=["auto", "general", "fused"])
+    ap.add_argument("--path", default="auto", choices=["auto", "general", "fused", "legacy"])
     ap.add_argument("--metric", default="l1_cv", choices=["l1_cv", "l2"],
                     help="l1_cv = the reference's cv2 transform (headline); l2 = exact Euclidean")
     args = ap.parse_args()

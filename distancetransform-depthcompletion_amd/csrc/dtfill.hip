@@ -64,6 +64,7 @@ namespace {
 #include "dtfill_prepass.hpp"
 #include "dtfill_fused.hpp"
 #include "dtfill_general.hpp"   // also k_colscan<true> used by the l2 pass
+#include "dtfill_rows.hpp"
 #include "dtfill_l2.hpp"
 #include "dtfill_outlier.hpp"
 #include "dtfill_gmc.hpp"
@@ -82,6 +83,9 @@ struct Carve {
     u64 *srcbits, *valbits;
     u16 *wpre_s, *wpre_v;
     u32 *rowcnt_s, *rowcnt_v, *rowbase_s, *rowbase_v;
+    u32 *ctT;            // k_colT -> k_rows: per 32-row band and column, the band's source bits of the column
+    u16 *ctU, *ctD;      // ... and the distance from the band's first / last row to the nearest source above / below
+    int nb;              // bands per frame
     int *finfo, *fflag, *fflag2, *status;
     float *vlist;
     size_t total;
@@ -112,12 +116,16 @@ Carve carve(void *ws, int B, int H, int W) {
     c.fflag = (int *)take((size_t)B * 4);
     c.fflag2 = (int *)take((size_t)B * 4);
     c.status = (int *)take((size_t)B * 4);
-    // general-path arrays (touched only for frames the fused kernel flags)
+    // any-distance path (touched only for frames the fused kernel does not take)
+    c.nb = (H + 31) / 32;
+    c.ctT = (u32 *)take((size_t)B * c.nb * W * 4);
+    c.ctU = (u16 *)take((size_t)B * c.nb * W * 2);
+    c.ctD = (u16 *)take((size_t)B * c.nb * W * 2);
     c.gu = (u16 *)take(N * 2);
     c.g = (u16 *)take(N * 2);
     c.dB = (u16 *)take(N * 2);
     c.plane_bytes = align256(NW * 8);
-    c.planes = (u8 *)take(4 * c.plane_bytes);
+    c.planes = (u8 *)take(PL_N * c.plane_bytes);
     c.exitp = (u32 *)take(N * 4);
     c.vlist = (float *)take(N * 4);
     c.total = off;
@@ -129,9 +137,8 @@ bool shape_ok(int B, int H, int W) {
            (long long)B * H * W < (1ll << 31);  // B is a grid dimension; pixel indices are 32-bit
 }
 
-constexpr int NK_L1 = 8;
-const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame",   "k_fused", "k_colscan",
-                                     "k_skew", "k_rowscan", "k_exit",  "k_final"};
+constexpr int NK_L1 = 7;
+const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_colT", "k_rows", "k_ties", "k_tiesx"};
 
 // k_mask4 when the rows can be read 16 bytes at a time, k_mask otherwise (same outputs)
 void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, float val_thr, const Carve &c, hipStream_t st) {
@@ -144,76 +151,98 @@ void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, flo
                                                                           c.rowcnt_v);
 }
 
+// the legacy any-distance kernels (column / knight-line / row scans through HBM, pointer doubling per tile)
+void launch_legacy_general(const float *x, int B, int H, int W, int Wd, const Carve &c, float *out_depth, float *out_dt,
+                           int32_t *out_index, int *status, hipStream_t st) {
+    const int N1 = H * W;
+    k_colscan<false><<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, c.fflag2, c.finfo, H, W, Wd, c.gu, c.g);
+    const int nU = W + 2 * (H - 1) + 1;
+    k_skew<<<dim3((nU + 63) / 64, B), 64 * G_NCH, 0, st>>>(c.gu, c.fflag2, c.finfo, H, W, c.dB);
+    const int nseg = (W + 511) / 512;
+    const size_t per_wave = (size_t)nseg * 512 * sizeof(int);  // <= 32 KiB at W = 8191
+    const int wpb = (int)max((size_t)1, min((size_t)4, (size_t)65536 / per_wave));
+    k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag2, c.finfo, H, W, nseg,
+                                                                          Wd * 8, c.planes, c.plane_bytes, out_dt);
+    const int etx = (W + X_T - 1) / X_T, ety = (H + X_T - 1) / X_T;
+    k_exit<<<dim3(etx * ety, B), X_NT, 0, st>>>(c.planes, c.plane_bytes, Wd * 8, c.srcbits, Wd, c.finfo, c.fflag2, H, W, etx,
+                                                c.exitp, -1);
+    k_final<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(x, c.exitp, c.srcbits, c.wpre_s, c.rowbase_s,
+                                                                             c.finfo, c.vlist, c.fflag2, H, W, Wd,
+                                                                             out_depth, out_index, status);
+}
+
 int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, float *out_depth,
            float *out_dt, int32_t *out_index, int32_t *frame_status, void *workspace, unsigned flags,
            hipStream_t st, hipEvent_t *ev) {
     const Carve c = carve(workspace, B, H, W);
     const int Wd = (W + 63) / 64;
-    const int N1 = H * W;
     int *status = frame_status ? frame_status : c.status;
     const bool general_only = flags & DTFILL_FLAG_GENERAL_ONLY;
     const bool fused_only = flags & DTFILL_FLAG_FUSED_ONLY;
-    // debug: DTFILL_FUSED_STOP=n makes k_fused return after phase n (timing only, outputs undefined)
-    const char *stop_env = ev ? getenv("DTFILL_FUSED_STOP") : nullptr;
-    const int fused_stop = stop_env ? atoi(stop_env) : -1;
-    const char *xstop_env = ev ? getenv("DTFILL_EXIT_STOP") : nullptr;
-    const int exit_stop = xstop_env ? atoi(xstop_env) : -1;
+    const bool legacy = flags & DTFILL_FLAG_LEGACY_GENERAL;
     int k = 0;
+    bool ok = true;
     auto mark = [&]() {
+        ok = ok && hipGetLastError() == hipSuccess;  // after every launch
         if (ev) (void)hipEventRecord(ev[k++], st);
     };
     mark();
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s,
-                               c.rowbase_v, c.finfo, c.vlist, c.fflag, c.fflag2, status, (general_only ? 1 : 0) | (fused_only ? 2 : 0));
+                               c.rowbase_v, c.finfo, c.vlist, c.fflag, c.fflag2, status, (general_only ? 1 : 0) | 2);
     mark();
     if (!general_only) {
-        // stage 1: halo 16 (tiles up to 96 x 160); stage 2, only for frames stage 1 flagged: halo 32
-        {
-            constexpr int R = 16, THM = F_WHM - 2 * R, TWM = F_WWM - 2 * R;
-            const int nty = (H + THM - 1) / THM, ntx = (W + TWM - 1) / TWM;
-            const int TH = (H + nty - 1) / nty, TW = (W + ntx - 1) / ntx;  // even split
-            k_fused<R><<<dim3(ntx * nty, B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist,
-                                                           H, W, Wd, TH, TW, ntx, out_depth, out_dt, out_index,
-                                                           nullptr, c.fflag, status, fused_stop);
-        }
-        {
-            constexpr int R = 32, THM = F_WHM - 2 * R, TWM = F_WWM - 2 * R;
-            const int nty = (H + THM - 1) / THM, ntx = (W + TWM - 1) / TWM;
-            const int TH = (H + nty - 1) / nty, TW = (W + ntx - 1) / ntx;
-            k_fused<R><<<dim3(ntx * nty, B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist,
-                                                           H, W, Wd, TH, TW, ntx, out_depth, out_dt, out_index,
-                                                           c.fflag, c.fflag2, status, -1);
-        }
+        // dense frames: one window kernel (halo 16).  It hands a frame on (fflag2) when the frame is too sparse for
+        // the halo or a tile pixel turns out to be farther than 16 from every source.
+        constexpr int R = 16, THM = F_WHM - 2 * R, TWM = F_WWM - 2 * R;
+        const int nty = (H + THM - 1) / THM, ntx = (W + TWM - 1) / TWM;
+        const int TH = (H + nty - 1) / nty, TW = (W + ntx - 1) / ntx;  // even split
+        k_fused<R><<<dim3(ntx * nty, B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd,
+                                                       TH, TW, ntx, out_depth, out_dt, out_index, nullptr, c.fflag2,
+                                                       status);
     }
     mark();
-    if (!fused_only) {
-        k_colscan<false><<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, c.fflag2, c.finfo, H, W, Wd, c.gu, c.g);
+    if (!fused_only && legacy) {
+        launch_legacy_general(x, B, H, W, Wd, c, out_depth, out_dt, out_index, status, st);
+        for (int t = 0; t < 4; ++t) mark();
+    } else if (!fused_only) {
+        // every other frame: argmin scans, any distance (dtfill_rows.hpp)
+        const int nb = c.nb;
+        const int cw = min(16, max(2, nb));
+        k_colT<<<dim3(Wd, B), 64 * cw, (size_t)nb * 64 * 2 * sizeof(u16), st>>>(c.srcbits, c.fflag2, H, W, Wd, nb, c.ctT,
+                                                                               c.ctU, c.ctD);
         mark();
-        const int nU = W + 2 * (H - 1) + 1;
-        k_skew<<<dim3((nU + 63) / 64, B), 64 * G_NCH, 0, st>>>(c.gu, c.fflag2, c.finfo, H, W, c.dB);
+        const int nwv = (W + 511) / 512;
+        const int Wp = Wd * 8;
+        auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        const int ovec = aligned16(out_depth) && aligned16(out_dt) && aligned16(out_index);
+        if ((W & 7) == 0)
+            k_rows<true><<<dim3(H, B), 64 * nwv, 0, st>>>(x, c.ctT, c.ctU, c.ctD, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo,
+                                                          c.vlist, c.fflag2, H, W, Wd, nb, Wp, c.planes, c.plane_bytes,
+                                                          out_depth, out_dt, out_index, status, ovec);
+        else
+            k_rows<false><<<dim3(H, B), 64 * nwv, 0, st>>>(x, c.ctT, c.ctU, c.ctD, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo,
+                                                           c.vlist, c.fflag2, H, W, Wd, nb, Wp, c.planes, c.plane_bytes,
+                                                           out_depth, out_dt, out_index, status, 0);
         mark();
-        const int nseg = (W + 511) / 512;
-        const size_t per_wave = (size_t)nseg * 512 * sizeof(int);  // <= 32 KiB at W = 8191
-        const int wpb = (int)max((size_t)1, min((size_t)4, (size_t)65536 / per_wave));
-        k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag2, c.finfo, H, W,
-                                                                              nseg, Wd * 8, c.planes, c.plane_bytes, out_dt);
-        mark();
-        {
-            const int etx = (W + X_T - 1) / X_T, ety = (H + X_T - 1) / X_T;
-            k_exit<<<dim3(etx * ety, B), X_NT, 0, st>>>(c.planes, c.plane_bytes, Wd * 8, c.srcbits, Wd, c.finfo, c.fflag2, H,
-                                                        W, etx, c.exitp, exit_stop);
+        if (out_depth || out_index) {  // the distance map needs no tie-break
+            const int ttx = (W + Q_TW - 1) / Q_TW, tty = (H + Q_TH - 1) / Q_TH;
+            k_ties<<<dim3(ttx * tty, B), Q_NT, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, ttx, out_depth,
+                                                        out_index, c.planes + PL_UNRES * c.plane_bytes);
+            mark();
+            const int nw = H * (Wp >> 2);
+            k_tiesx<<<dim3((nw + 255) / 256, B), 256, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, out_depth,
+                                                               out_index);
+            mark();
+        } else {
+            mark();
+            mark();
         }
-        mark();
-        k_final<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(
-            x, c.exitp, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, c.fflag2, H, W, Wd, out_depth, out_index,
-            status);
-        mark();
     } else {
-        for (int t = 0; t < 5; ++t) mark();
+        for (int t = 0; t < 4; ++t) mark();
     }
-    return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
+    return ok ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
 
 constexpr int NK_L2 = 4;

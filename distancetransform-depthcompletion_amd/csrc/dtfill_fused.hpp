@@ -256,7 +256,7 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
     int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
     float *__restrict__ out_dt, int32_t *__restrict__ out_index, const int *__restrict__ gate,
-    int *__restrict__ fflag, int *__restrict__ frame_status, int stop_after) {
+    int *__restrict__ fflag, int *__restrict__ frame_status) {
     if (gate && !gate[blockIdx.y]) return;
     // Speed heuristic only (never correctness): with source density p the chance that a pixel has no source
     // within L1 distance FR is about (1-p)^(2 FR^2 + 2 FR + 1); if the frame is expected to hold such a pixel
@@ -346,11 +346,7 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
         // one writer per frame: the LAST tile (bottom right) -- in band mode the first tiles have returned above
         if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {
             fflag[blockIdx.y] = 1;
-            if (FR == 32) {  // last fused stage: the WHOLE frame takes the general path (leaves band mode)
-                atomicOr(frame_status + blockIdx.y, DTFILL_FRAME_GENERAL_PATH);
-                finfo[blockIdx.y * FI_STRIDE + FI_RW] = H;
-                finfo[blockIdx.y * FI_STRIDE + FI_HG] = H;
-            }
+            atomicOr(frame_status + blockIdx.y, DTFILL_FRAME_GENERAL_PATH);
         }
         return;
     }
@@ -373,7 +369,6 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
 #pragma unroll
     for (int i = 0; i < F_HW; ++i) Dup[i] = Ddn[i] = 0;
     __syncthreads();
-    if (stop_after == 0) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
     // ---- P1: levels.  Per level: E_t (dilation), L_t (forward taps, winners recorded), d mod 8 planes.
     u32 P0[F_HW], P1[F_HW], P2[F_HW];  // bits 0..2 of the level at which a pixel was decided (sources: 0)
@@ -487,7 +482,6 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
         row4(r + 2);
         bwd_tap<1, 1, 36 - ENC_F(7)>(a0, a1, a2, dv, P0, P1, P2, taken, C);
     }
-    if (stop_after == 1) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
     // ---- P2: un-slice the code planes of this half row into bytes, 4 pixels per step.
     // ((nibble * 0x00204081) & 0x01010101) spreads bits 0..3 of the nibble to the low bits of 4 bytes
@@ -514,16 +508,11 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
         }
     }
     __syncthreads();
-    if (stop_after == 2) return;  // timing-only builds of bench (DTFILL_FUSED_STOP)
 
     const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_tab, s_rw, b, H, W, th, tw, r0, c0, wr0, wc0, sh, rw_lo, x, vlist,
                                                         finfo, out_depth, out_dt, out_index, frame_status);
     if (overflow) {
-        fflag[b] = 1;  // same-value race
-        if (FR == 32) {  // last fused stage: the WHOLE frame takes the general path next (leaves band mode)
-            atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);
-            finfo[b * FI_STRIDE + FI_RW] = H;
-            finfo[b * FI_STRIDE + FI_HG] = H;
-        }
+        fflag[b] = 1;  // same-value race: every writer stores 1, the any-distance kernels read it after this kernel
+        atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);
     }
 }

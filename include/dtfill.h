@@ -63,6 +63,7 @@ extern "C" {
 #define DTFILL_FLAG_GENERAL_ONLY 1u /* skip the fused tile kernels, every frame takes the general path */
 #define DTFILL_FLAG_FUSED_ONLY   2u /* skip the general kernels: frames that need them are left
                                        undefined and carry DTFILL_FRAME_GENERAL_PATH in their status */
+#define DTFILL_FLAG_LEGACY_GENERAL 4u /* any-distance frames through the round-1 kernels (A/B tests only) */
 
 int dtfill_abi_version(void);
 const char *dtfill_strerror(int code);

@@ -203,11 +203,12 @@ def test_fused_kernel_alone_decides_dense_frames(gpu_op, oracle, pkg):
     got = run(gpu_op, x, path="fused")
     assert not got["general"].any()
     assert np.array_equal(got["dt"], dt) and np.array_equal(got["index"], lbl) and np.array_equal(got["depth"], depth)
-    # an empty band of 40 rows: distances up to ~25 -> beyond the halo-16 stage, within the halo-32 stage
-    x[1, 100:140] = 0
-    # an empty band of 90 rows: distances up to ~45 -> only the general (any-distance) kernels can decide it
+    # an empty band of 10 rows: still within the halo
+    x[1, 100:110] = 0
+    # an empty band of 90 rows: distances up to ~45 -> only the any-distance kernels can decide it
     x[2, 100:190] = 0
     depth2, dt2, lbl2, _ = oracle.fill_batch(x)
+    assert dt2[1].max() <= 16 < dt2[2].max()
     got = run(gpu_op, x, path="fused")
     assert got["general"].tolist() == [False, False, True, False]
     for b in (0, 1, 3):
@@ -419,13 +420,14 @@ def test_single_undecided_pixel_in_every_byte_lane(gpu_op, oracle):
     is a source, the corner pixel is R away from it), for the four positions the pixel can have inside the
     4-pixel groups the kernel un-slices.  The stage must notice that single pixel and hand the frame on: a
     lost "undecided" code in one byte lane once let it through with a garbage label (found by scripts/soak.py)."""
-    for R, widths, general in ((17, (157, 158, 159, 160), False), (33, (125, 126, 127, 128), True)):
+    for R, widths, general in ((16, (157, 158, 159, 160), False), (17, (157, 158, 159, 160), True), (33, (125, 126, 127, 128), True)):
         for W in widths:
             H = 40
             i, j = np.mgrid[0:H, 0:W]
             x = np.where(i + (W - 1 - j) >= R, 5.0 + 0.01 * ((i * 7 + j * 3) % 97), 0.0).astype(np.float32)[None]
             depth, dt, lbl, status = oracle.fill_batch(x, 0.1, 0.1)
             assert dt[0, 0, W - 1] == R and (dt[0] > R - 1).sum() == 1
+            assert bool(dt[0].max() > 16) == general
             got = run(gpu_op, x, path="auto")
             assert np.array_equal(got["dt"], dt) and np.array_equal(got["index"], lbl), (R, W)
             assert np.array_equal(got["depth"], depth) and bool(got["general"][0]) == general, (R, W)
@@ -434,6 +436,39 @@ def test_single_undecided_pixel_in_every_byte_lane(gpu_op, oracle):
             depth, dt, lbl, status = oracle.fill_batch(xm, 0.1, 0.1)
             got = run(gpu_op, xm, path="auto")
             assert np.array_equal(got["dt"], dt) and np.array_equal(got["index"], lbl), (R, W, "mirrored")
+
+
+def test_tie_regions_and_long_tie_chains(gpu_op, oracle):
+    """The any-distance kernels decide a pixel with ONE nearest source without a chain; tie pixels hop until they
+    stand on such a pixel.  Inputs that stress exactly that: two sources on a diagonal (a whole quadrant is
+    equidistant from both: chains of tie pixels that run for hundreds of hops, far beyond k_ties' window, so
+    k_tiesx finishes them), lattices (every pixel between four sources ties), a single source (no ties at all),
+    sources only in one row / one column, and two far-apart points."""
+    frames = []
+    a = np.zeros((300, 420), np.float32); a[250, 60] = 1.5; a[246, 64] = 2.5; frames.append(a)
+    a = np.zeros((300, 420), np.float32); a[20, 300] = 1.5; a[24, 304] = 2.5; a[150, 100] = 3.5; frames.append(a)
+    a = np.zeros((300, 420), np.float32); a[::25, ::30] = 4.0; frames.append(a)
+    a = np.zeros((300, 420), np.float32); a[123, 321] = 4.0; frames.append(a)
+    a = np.zeros((300, 420), np.float32); a[299, ::7] = 5.0; frames.append(a)
+    a = np.zeros((300, 420), np.float32); a[::9, 0] = 6.0; frames.append(a)
+    a = np.zeros((300, 420), np.float32); a[0, 0] = 6.0; a[299, 419] = 7.0; frames.append(a)
+    a = np.zeros((300, 420), np.float32); a[100, 100] = 6.0; a[100, 140] = 7.0; a[140, 100] = 8.0; a[140, 140] = 9.0
+    frames.append(a)
+    x = np.stack(frames)
+    assert_equal_to_oracle(oracle, gpu_op, x, paths=("general", "auto"))
+    for want in (("depth",), ("index",), ("dt",), ("depth", "index")):
+        depth, dt, lbl, _ = oracle.fill_batch(x)
+        got = run(gpu_op, x, want=want, path="general")
+        for k, ref in (("depth", depth), ("dt", dt), ("index", lbl)):
+            if k in want:
+                assert np.array_equal(got[k], ref), (want, k)
+    # widths that are not a multiple of 8 (scalar loads / stores) and of 32 (ragged last plane word)
+    rng = np.random.default_rng(31)
+    for H, W in [(70, 70), (33, 97), (64, 130), (100, 1030)]:
+        y = np.where(rng.random((3, H, W)) < 0.004, rng.uniform(1, 80, (3, H, W)), 0).astype(np.float32)
+        y[2, H // 3, W // 3] = 2.0
+        y[2, H // 3 - 5, W // 3 + 5] = 3.0
+        assert_equal_to_oracle(oracle, gpu_op, y, paths=("general",))
 
 
 def test_input_pointer_alignment_does_not_matter(gpu_op, oracle):
@@ -456,11 +491,11 @@ def test_input_pointer_alignment_does_not_matter(gpu_op, oracle):
         assert np.array_equal(res["depth"].cpu().numpy(), depth), off
 
 
-def test_band_mode_and_its_ways_out(gpu_op, oracle):
-    """An empty band on top of a dense frame: the general kernels own the band, the fused stages the rest (band
-    mode).  Variants: a hole below the band that stage 2 can still decide; a hole beyond both halos (the whole frame
-    must leave band mode); a band too tall for the margin to fit; bands at the bottom / in the middle (no band mode:
-    whole frame general); band + differing thresholds (value list gather)."""
+def test_empty_bands_in_dense_frames(gpu_op, oracle):
+    """An empty band (the sky of a LiDAR frame) on top of, below or inside an otherwise dense frame, holes of
+    several sizes below it, bands of several heights around the window kernel's halo (16): whichever kernel family
+    takes the frame, the maps are the oracle's.  Also with differing thresholds (value list gather), next to
+    dense frames in one batch, and with each subset of the outputs."""
     rng = np.random.default_rng(77)
     H, W = 352, 640
 
@@ -480,13 +515,13 @@ def test_band_mode_and_its_ways_out(gpu_op, oracle):
     x = np.stack(frames)
     assert_equal_to_oracle(oracle, gpu_op, x)
     got = run(gpu_op, x, path="auto")
-    assert got["general"][:7].all() and not got["general"][8]
+    assert got["general"][:8].all()  # every one of them holds a pixel farther than 16 from all sources
     # a band with thresholds that make the value list differ from the source list
     assert_equal_to_oracle(oracle, gpu_op, x[:2], st=0.1, vt=30.0)
-    # one frame in band mode next to frames that are not
+    # one such frame between dense frames (two kernel families in one batch)
     mix = np.stack([dense(), frames[0], dense(0.3)])
     assert_equal_to_oracle(oracle, gpu_op, mix)
-    # optional outputs in band mode: each map is written by two kernel families (rows above / below the band)
+    # optional outputs
     depth, dt, lbl, status = oracle.fill_batch(mix, 0.1, 0.1)
     for want in (("index",), ("dt",), ("depth",), ("depth", "dt")):
         got = run(gpu_op, mix, want=want)
@@ -495,9 +530,8 @@ def test_band_mode_and_its_ways_out(gpu_op, oracle):
                 assert np.array_equal(got[k], ref), (want, k)
 
 
-def test_band_mode_with_stray_points_in_the_sky(gpu_op, oracle):
-    """The band need not be perfectly empty: a few sources inside it split the leading run, the band then ends
-    with the last run of empty rows that is beyond the fused halos."""
+def test_stray_points_in_the_sky(gpu_op, oracle):
+    """The band need not be perfectly empty: a few sources inside it."""
     rng = np.random.default_rng(78)
     H, W = 352, 640
     frames = []
