@@ -83,9 +83,10 @@ struct Carve {
     u64 *srcbits, *valbits;
     u16 *wpre_s, *wpre_v;
     u32 *rowcnt_s, *rowcnt_v, *rowbase_s, *rowbase_v;
-    u32 *ctT;            // k_colT -> k_rows: per 32-row band and column, the band's source bits of the column
-    u16 *ctU, *ctD;      // ... and the distance from the band's first / last row to the nearest source above / below
-    int nb;              // bands per frame
+    uint2 *ct;           // k_colT -> k_rows: per 32-row band and column {the band's source bits of the column, distances
+                         // from the band's first / last row to the nearest source above / below}; rows of ctp columns
+    int nb, ctp;         // bands per frame, columns per row of ct
+    u32 *xlist, *xptr;   // k_ties -> k_tiesx: the pixels whose chain left their tile, and where each goes on
     int *finfo, *fflag, *fflag2, *status;
     float *vlist;
     size_t total;
@@ -118,9 +119,10 @@ Carve carve(void *ws, int B, int H, int W) {
     c.status = (int *)take((size_t)B * 4);
     // any-distance path (touched only for frames the fused kernel does not take)
     c.nb = (H + 31) / 32;
-    c.ctT = (u32 *)take((size_t)B * c.nb * W * 4);
-    c.ctU = (u16 *)take((size_t)B * c.nb * W * 2);
-    c.ctD = (u16 *)take((size_t)B * c.nb * W * 2);
+    c.ctp = ct_pitch(W);
+    c.ct = (uint2 *)take((size_t)B * c.nb * c.ctp * sizeof(uint2));
+    c.xlist = (u32 *)take(N * 4);
+    c.xptr = (u32 *)take(N * 4);
     c.gu = (u16 *)take(N * 2);
     c.g = (u16 *)take(N * 2);
     c.dB = (u16 *)take(N * 2);
@@ -210,30 +212,41 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         // every other frame: argmin scans, any distance (dtfill_rows.hpp)
         const int nb = c.nb;
         const int cw = min(16, max(2, nb));
-        k_colT<<<dim3(Wd, B), 64 * cw, (size_t)nb * 64 * 2 * sizeof(u16), st>>>(c.srcbits, c.fflag2, H, W, Wd, nb, c.ctT,
-                                                                               c.ctU, c.ctD);
+        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, (size_t)nb * 64 * 2 * sizeof(u16), st>>>(c.srcbits, c.fflag2, H, W, Wd, nb,
+                                                                                         c.ctp, c.ct);
         mark();
-        const int nwv = (W + 511) / 512;
         const int Wp = Wd * 8;
-        auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-        const int ovec = aligned16(out_depth) && aligned16(out_dt) && aligned16(out_index);
-        if ((W & 7) == 0)
-            k_rows<true><<<dim3(H, B), 64 * nwv, 0, st>>>(x, c.ctT, c.ctU, c.ctD, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo,
-                                                          c.vlist, c.fflag2, H, W, Wd, nb, Wp, c.planes, c.plane_bytes,
-                                                          out_depth, out_dt, out_index, status, ovec);
+        // columns per lane: 8 or 10, whichever leaves fewer idle lanes in the row's last wave
+        const int nw8 = (W + 511) / 512, nw10 = (W + 639) / 640;
+        const bool ten = nw10 * 640 < nw8 * 512;
+        auto aligned = [](const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+        const int nwv = ten ? nw10 : nw8;
+        const int ovec = ten ? ((W & 1) == 0 && aligned(out_depth, 8) && aligned(out_dt, 8) && aligned(out_index, 8))
+                             : ((W & 3) == 0 && aligned(out_depth, 16) && aligned(out_dt, 16) && aligned(out_index, 16));
+        const dim3 grid(H, B);
+#define LAUNCH_ROWS(PPL_, MAXT_)                                                                                         \
+    k_rows<PPL_, MAXT_><<<grid, 64 * nwv, 0, st>>>(x, c.ct, c.ctp, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist,     \
+                                                   c.fflag2, H, W, Wd, nb, Wp, c.planes, c.plane_bytes, out_depth, out_dt, \
+                                                   out_index, status, ovec)
+        if (ten && nwv <= 4)
+            LAUNCH_ROWS(10, 256);
+        else if (ten)
+            LAUNCH_ROWS(10, 1024);
+        else if (nwv <= 4)
+            LAUNCH_ROWS(8, 256);
         else
-            k_rows<false><<<dim3(H, B), 64 * nwv, 0, st>>>(x, c.ctT, c.ctU, c.ctD, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo,
-                                                           c.vlist, c.fflag2, H, W, Wd, nb, Wp, c.planes, c.plane_bytes,
-                                                           out_depth, out_dt, out_index, status, 0);
+            LAUNCH_ROWS(8, 1024);
+#undef LAUNCH_ROWS
         mark();
         if (out_depth || out_index) {  // the distance map needs no tie-break
+            const int Wp = Wd * 8;
             const int ttx = (W + Q_TW - 1) / Q_TW, tty = (H + Q_TH - 1) / Q_TH;
             k_ties<<<dim3(ttx * tty, B), Q_NT, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, ttx, out_depth,
-                                                        out_index, c.planes + PL_UNRES * c.plane_bytes);
+                                                        out_index, c.finfo, c.xlist, c.xptr,
+                                                        c.planes + PL_UNRES * c.plane_bytes);
             mark();
-            const int nw = H * (Wp >> 2);
-            k_tiesx<<<dim3((nw + 255) / 256, B), 256, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, out_depth,
-                                                               out_index);
+            k_tiesx<<<dim3(XL_BLOCKS, B), 256, 0, st>>>(c.planes + PL_UNRES * c.plane_bytes, Wp, c.fflag2, c.finfo, c.xlist,
+                                                        c.xptr, H, W, out_depth, out_index);
             mark();
         } else {
             mark();

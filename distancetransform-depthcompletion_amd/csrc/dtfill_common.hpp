@@ -16,6 +16,7 @@ constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_DLB = 3;  // DLB: 
 // Band mode (an empty band on top of an otherwise dense frame): the general kernels own rows [0, RW) and
 // compute on rows [0, HG) only, the fused stages own rows [RW, H).  Otherwise RW = HG = H.
 constexpr int FI_RW = 4, FI_HG = 5, FI_STRIDE = 8;
+constexpr int FI_NUNRES = 6;  // tie pixels k_ties handed to k_tiesx (zeroed by k_frame)
 constexpr int BAND_MARGIN = 65;  // HG = RW + 2 * 32 + 1: no source at or beyond that row can be nearest to (or tie for) a pixel above RW
 
 // cv2 tap order (OpenCV 3.4 distanceTransformEx_5x5), forward taps 0..7; backward tap t is the

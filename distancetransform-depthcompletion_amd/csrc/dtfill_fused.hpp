@@ -258,14 +258,13 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     float *__restrict__ out_dt, int32_t *__restrict__ out_index, const int *__restrict__ gate,
     int *__restrict__ fflag, int *__restrict__ frame_status) {
     if (gate && !gate[blockIdx.y]) return;
+    if (fflag[blockIdx.y]) return;  // the any-distance kernels take this frame (k_frame's choice)
     // Speed heuristic only (never correctness): with source density p the chance that a pixel has no source
     // within L1 distance FR is about (1-p)^(2 FR^2 + 2 FR + 1); if the frame is expected to hold such a pixel
     // anyway (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), this stage would only flag the frame after doing
     // all the work -- hand it on right away.  Likewise when k_frame found a run of source-free rows that forces
     // some distance above FR (real LiDAR frames: the empty sky rows).  (The two finfo loads are issued together
     // with the window loads below; the branch comes after those are in flight.)
-    const long long h_nsrc = finfo[blockIdx.y * FI_STRIDE + FI_NSRC];
-    const int h_dlb = finfo[blockIdx.y * FI_STRIDE + FI_DLB];
     const int h_rw = finfo[blockIdx.y * FI_STRIDE + FI_RW];  // band mode (h_rw < H): rows above belong to the general kernels
     __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
     // per window row, the eight image-aligned 32-pixel half words it touches: {source bits, sources before them
@@ -341,14 +340,6 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
             if (r >= FR && r < FR + th && r0 + r - FR >= rw_lo && tup > tlo) tm = (tup >= 32 ? 0xFFFFFFFFu : ((1u << tup) - 1u)) & ~((1u << tlo) - 1u);
             TM[i] = tm;
         }
-    }
-    if (h_nsrc * (2 * FR * FR + 2 * FR + 1) < 14ll * (H - rw_lo) * W || h_dlb > FR) {  // block-uniform
-        // one writer per frame: the LAST tile (bottom right) -- in band mode the first tiles have returned above
-        if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) {
-            fflag[blockIdx.y] = 1;
-            atomicOr(frame_status + blockIdx.y, DTFILL_FRAME_GENERAL_PATH);
-        }
-        return;
     }
     // level 0: E_0 = L_0 = sources; zero the rest of the ring (levels "-1,-2,-3", the guard rows, the pads)
     for (int k = tid; k < F_RING; k += F_NT) s_ring[k] = 0;

@@ -181,19 +181,16 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
                                                int *__restrict__ finfo, float *__restrict__ vlist,
                                                int *__restrict__ fflag, int *__restrict__ fflag2,
                                                int *__restrict__ frame_status, int mode) {
-    const bool force_general = mode & 1;  // every frame takes the general kernels (tests)
-    const bool no_band = mode & 2;        // the general kernels will not run at all (tests; the l2 pass): no band mode
+    const bool force_general = mode & 1;  // every frame takes the any-distance kernels (tests)
     __shared__ u32 s_ws[4], s_wv[4];
-    __shared__ int s_mis, s_dlb, s_k0, s_rest;  // s_k0: end row of the band (0: none)
+    __shared__ int s_mis, s_dlb;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 *cs_ = rowcnt_s + (size_t)b * H, *cv_ = rowcnt_v + (size_t)b * H;
-    if (tid == 0) {
-        s_dlb = 0;
-        s_k0 = 0;
-        s_rest = 0;
-    }
     u32 *bs_ = rowbase_s + (size_t)b * H, *bv_ = rowbase_v + (size_t)b * H;
-    if (tid == 0) s_mis = 0;
+    if (tid == 0) {
+        s_mis = 0;
+        s_dlb = 0;
+    }
     __syncthreads();
     u32 run_s = 0, run_v = 0;
     int mis = 0;
@@ -239,89 +236,56 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         __syncthreads();
     }
     if (mis) atomicOr(&s_mis, 1);
-    // Lower bound of the largest distance in the frame from runs of rows without any source: a run of k
-    // empty rows forces d >= ceil(k/2) in its middle row, d >= k at the border row if it touches the top or
-    // bottom edge.  Each thread looks at the run ENDING at its rows (cheap: the counts are in L2).
+    // Lower bound of the largest distance in the frame from runs of rows without any source: a run of k empty rows
+    // forces d >= ceil(k/2) in its middle row, d >= k at the border row if it touches the top or bottom edge.
+    // "Row has no source" as bits in LDS (H <= 8191 -> 256 words); each thread looks at the runs ENDING at its rows.
     {
-        // "row has no source" as bits in LDS (H <= 8191 -> 256 words), and "sky row": fewer than one source per 64
-        // columns within the 33 rows around it (from the row prefix sums this block has just written) -- what the
-        // band detection looks at; a frame that is thin everywhere but evenly so has no sky rows
-        __shared__ u32 s_empty[256], s_sparse[256];
+        __shared__ u32 s_empty[256];
         s_empty[tid] = 0;
-        s_sparse[tid] = 0;
-        __syncthreads();  // also makes this block's bs_ stores visible to its own loads below
-        for (int i = tid; i < H; i += 256) {
-            if (cs_[i] == 0) atomicOr(&s_empty[i >> 5], 1u << (i & 31));
-            const int lo = max(i - 16, 0), hi = min(i + 17, H);
-            const u32 around = (hi < H ? bs_[hi] : run_s) - bs_[lo];
-            if (around * 64u < (u32)W) atomicOr(&s_sparse[i >> 5], 1u << (i & 31));
-        }
         __syncthreads();
-        auto empty = [&](int i) { return (s_empty[i >> 5] >> (i & 31)) & 1u; };
-        auto sparse = [&](int i) { return (s_sparse[i >> 5] >> (i & 31)) & 1u; };
-        // first row of the run of set bits that ends at row i (bit i is set): whole words at a time
-        auto run_start = [&](const u32 *bm, int i) {
-            int w = i >> 5;
-            const u32 zeros_below = ~bm[w] & ((2u << (i & 31)) - 1u);  // cleared bits at or below bit i of this word
-            if (zeros_below) return w * 32 + 32 - __clz((int)zeros_below);
-            while (w > 0 && bm[w - 1] == 0xFFFFFFFFu) --w;
-            if (w == 0) return 0;
-            return (w - 1) * 32 + 32 - __clz((int)~bm[w - 1]);
-        };
-        // Per run of source-free rows (each thread looks at the runs ENDING at its rows): the distance it forces;
-        // s_dlb = the largest one (a true lower bound of the frame's largest distance).
-        // Band detection (a guess, never a correctness condition): s_k0 = end of the last run of SKY rows that
-        // would be beyond both fused halos if it were empty and does not touch the bottom edge -- everything above
-        // that row is the band of "band mode" (the sky of a LiDAR frame, with or without stray points in it).
-        auto forced = [&](int i, int &start) {  // run ending at row i (caller checked that it ends there)
-            start = run_start(s_empty, i);
+        for (int i = tid; i < H; i += 256)
+            if (cs_[i] == 0) atomicOr(&s_empty[i >> 5], 1u << (i & 31));
+        __syncthreads();
+        int dlb = 0;
+        for (int i = tid; i < H; i += 256) {
+            const bool e = (s_empty[i >> 5] >> (i & 31)) & 1u;
+            const bool enext = i + 1 < H && ((s_empty[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
+            if (!e || enext) continue;  // not the last row of a run
+            // first row of the run of set bits that ends at row i: whole words at a time
+            int w = i >> 5, start;
+            const u32 zeros_below = ~s_empty[w] & ((2u << (i & 31)) - 1u);  // cleared bits at or below bit i of this word
+            if (zeros_below) {
+                start = w * 32 + 32 - __clz((int)zeros_below);
+            } else {
+                while (w > 0 && s_empty[w - 1] == 0xFFFFFFFFu) --w;
+                start = w == 0 ? 0 : (w - 1) * 32 + 32 - __clz((int)~s_empty[w - 1]);
+            }
             const int k = i - start + 1;
             const bool top = start == 0, bottom = i + 1 >= H;
-            return (top && bottom) ? BIG : (top || bottom) ? k : (k + 1) / 2;
-        };
-        int dlb = 0, rbad = 0;
-        for (int i = tid; i < H; i += 256) {
-            if (sparse(i) && i + 1 < H && !sparse(i + 1)) {  // last row of a run of sky rows, not at the bottom
-                const int st = run_start(s_sparse, i), k = i - st + 1;
-                if ((st == 0 ? k : (k + 1) / 2) > 32) {  // same bound, as if those rows were empty
-                    int e = i + 1;  // the last rows of the sky see the sources below it in their window: take the
-                    while (e < H && empty(e)) ++e;  // source-free rows that follow (at most 16) into the band
-                    if (e < H) rbad = e;
-                }
-            }
-            if (!empty(i) || (i + 1 < H && empty(i + 1))) continue;  // not the last row of a run
-            int start;
-            dlb = max(dlb, forced(i, start));
+            dlb = max(dlb, (top && bottom) ? BIG : (top || bottom) ? k : (k + 1) / 2);
         }
         if (dlb) atomicMax(&s_dlb, dlb);
-        if (rbad) atomicMax(&s_k0, rbad);
-        __syncthreads();
-        // what the rows below the band still force
-        const int Rb = s_k0;
-        if (Rb > 0 && Rb + BAND_MARGIN < H) {  // block-uniform
-            int rest = 0;
-            for (int i = tid; i < H; i += 256) {
-                if (i < Rb || !empty(i) || (i + 1 < H && empty(i + 1))) continue;
-                int start;
-                rest = max(rest, forced(i, start));
-            }
-            if (rest) atomicMax(&s_rest, rest);
-        }
     }
     __syncthreads();
     const int misaligned = s_mis;
     if (tid == 0) {
-        const int Rb = s_k0;
-        const bool band = !force_general && !no_band && Rb > 0 && Rb + BAND_MARGIN < H && s_rest <= 32;
-        finfo[b * FI_STRIDE + FI_RW] = band ? Rb : H;
-        finfo[b * FI_STRIDE + FI_HG] = band ? Rb + BAND_MARGIN : H;
+        finfo[b * FI_STRIDE + FI_RW] = H;
+        finfo[b * FI_STRIDE + FI_HG] = H;
         finfo[b * FI_STRIDE + FI_NSRC] = (int)run_s;
         finfo[b * FI_STRIDE + FI_NVAL] = (int)run_v;
         finfo[b * FI_STRIDE + FI_MISALIGNED] = misaligned;
-        finfo[b * FI_STRIDE + FI_DLB] = band ? s_rest : s_dlb;
-        fflag[b] = 0;                       // set by k_fused<16>: the frame needs a wider halo
-        const bool general = force_general || band;  // band mode: rows [0, RW) take the general kernels
-        fflag2[b] = general ? 1 : 0;  // also set by k_fused<32>: the whole frame needs the general path
+        finfo[b * FI_STRIDE + FI_DLB] = s_dlb;
+        finfo[b * FI_STRIDE + FI_NUNRES] = 0;
+        fflag[b] = 0;
+        // Which kernel family takes the frame -- a speed heuristic, never a correctness condition (the window kernel
+        // itself hands on every frame in which it meets a pixel it cannot decide).  With source density p the chance
+        // that a pixel has no source within L1 distance 16 is about (1-p)^545; if the frame is expected to hold such
+        // a pixel anyway (N (1-p)^545 > ~1, i.e. p * 545 < ln N ~ 14), or a run of source-free rows forces a distance
+        // above 16 (real LiDAR frames: the empty sky rows), the window kernel would only find that out after doing
+        // all its work: the any-distance kernels take the frame right away.
+        const bool sparse = (long long)run_s * (2 * 16 * 16 + 2 * 16 + 1) < 14ll * H * W || s_dlb > 16;
+        const bool general = force_general || sparse;
+        fflag2[b] = general ? 1 : 0;  // also set by k_fused when it meets a pixel farther than its halo
         frame_status[b] = general ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
     }
     if (misaligned) {
