@@ -86,7 +86,9 @@ struct Carve {
     uint2 *ct;           // k_colT -> k_rows: per 32-row band and column {the band's source bits of the column, distances
                          // from the band's first / last row to the nearest source above / below}; rows of ctp columns
     int nb, ctp;         // bands per frame, columns per row of ct
-    u32 *xlist, *xptr;   // k_ties -> k_tiesx: the pixels whose chain left their tile, and where each goes on
+    u32 *xlist, *xptr;   // k_fin -> k_tiesx: the pixels whose chain left their tile, and where each goes on
+    u32 *spix;           // k_rows -> k_fin: per pixel, the frame offset of its nearest source in column kmin
+    int32_t *labelmap;   // k_labels: at every source pixel, its label (1 + raster rank among the frame's sources)
     int *finfo, *fflag, *fflag2, *status;
     float *vlist;
     size_t total;
@@ -121,6 +123,8 @@ Carve carve(void *ws, int B, int H, int W) {
     c.nb = (H + 31) / 32;
     c.ctp = ct_pitch(W);
     c.ct = (uint2 *)take((size_t)B * c.nb * c.ctp * sizeof(uint2));
+    c.labelmap = (int32_t *)take(N * 4);
+    c.spix = (u32 *)take(N * 4);
     c.xlist = (u32 *)take(N * 4);
     c.xptr = (u32 *)take(N * 4);
     c.gu = (u16 *)take(N * 2);
@@ -139,8 +143,8 @@ bool shape_ok(int B, int H, int W) {
            (long long)B * H * W < (1ll << 31);  // B is a grid dimension; pixel indices are 32-bit
 }
 
-constexpr int NK_L1 = 7;
-const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_colT", "k_rows", "k_ties", "k_tiesx"};
+constexpr int NK_L1 = 8;
+const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_labels", "k_colT", "k_rows", "k_fin", "k_tiesx"};
 
 // k_mask4 when the rows can be read 16 bytes at a time, k_mask otherwise (same outputs)
 void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, float val_thr, const Carve &c, hipStream_t st) {
@@ -205,6 +209,9 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
                                                        status);
     }
     mark();
+    if (!fused_only && !legacy && (out_depth || out_index))  // label of every source pixel of the frames that go on
+        k_labels<<<dim3((H * Wd + 255) / 256, B), 256, 0, st>>>(c.srcbits, c.wpre_s, c.rowbase_s, c.fflag2, H, W, Wd, c.labelmap);
+    mark();
     if (!fused_only && legacy) {
         launch_legacy_general(x, B, H, W, Wd, c, out_depth, out_dt, out_index, status, st);
         for (int t = 0; t < 4; ++t) mark();
@@ -221,13 +228,13 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const bool ten = nw10 * 640 < nw8 * 512;
         auto aligned = [](const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
         const int nwv = ten ? nw10 : nw8;
-        const int ovec = ten ? ((W & 1) == 0 && aligned(out_depth, 8) && aligned(out_dt, 8) && aligned(out_index, 8))
-                             : ((W & 3) == 0 && aligned(out_depth, 16) && aligned(out_dt, 16) && aligned(out_index, 16));
+        const bool fin = out_depth || out_index;  // the distance map alone needs neither sources nor tie-breaks
+        float *dt = out_dt;
+        const int ovec = ten ? ((W & 1) == 0 && aligned(dt, 8)) : ((W & 3) == 0 && aligned(dt, 16));
         const dim3 grid(H, B);
-#define LAUNCH_ROWS(PPL_, MAXT_)                                                                                         \
-    k_rows<PPL_, MAXT_><<<grid, 64 * nwv, 0, st>>>(x, c.ct, c.ctp, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist,     \
-                                                   c.fflag2, H, W, Wd, nb, Wp, c.planes, c.plane_bytes, out_depth, out_dt, \
-                                                   out_index, status, ovec)
+#define LAUNCH_ROWS(PPL_, MAXT_)                                                                                      \
+    k_rows<PPL_, MAXT_><<<grid, 64 * nwv, 0, st>>>(c.ct, c.ctp, c.fflag2, H, W, nb, Wp, c.planes, c.plane_bytes, dt,    \
+                                                   fin ? c.spix : nullptr, ovec)
         if (ten && nwv <= 4)
             LAUNCH_ROWS(10, 256);
         else if (ten)
@@ -238,12 +245,12 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
             LAUNCH_ROWS(8, 1024);
 #undef LAUNCH_ROWS
         mark();
-        if (out_depth || out_index) {  // the distance map needs no tie-break
-            const int Wp = Wd * 8;
+        if (fin) {
             const int ttx = (W + Q_TW - 1) / Q_TW, tty = (H + Q_TH - 1) / Q_TH;
-            k_ties<<<dim3(ttx * tty, B), Q_NT, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, ttx, out_depth,
-                                                        out_index, c.finfo, c.xlist, c.xptr,
-                                                        c.planes + PL_UNRES * c.plane_bytes);
+            const int vec = (W & 3) == 0 && aligned(out_depth, 16) && aligned(out_index, 16);
+            k_fin<<<dim3(ttx * tty, B), Q_NT, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, Wd, ttx, c.spix, x, c.labelmap,
+                                                       c.vlist, out_depth, out_index, status, c.finfo,
+                                                       c.xlist, c.xptr, c.planes + PL_UNRES * c.plane_bytes, vec);
             mark();
             k_tiesx<<<dim3(XL_BLOCKS, B), 256, 0, st>>>(c.planes + PL_UNRES * c.plane_bytes, Wp, c.fflag2, c.finfo, c.xlist,
                                                         c.xptr, H, W, out_depth, out_index);

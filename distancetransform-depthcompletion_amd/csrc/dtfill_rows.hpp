@@ -30,6 +30,7 @@
 constexpr int GBIG = 16383;  // column distance when the column has no source (d >= 8192 <=> frame without sources)
 constexpr int K_OFF = 8192;  // left keys carry value - column + K_OFF
 constexpr int K_SH = 15;     // key = value << 15 | arg; arg = column << 2 | flags, or (8191 - column) << 2
+constexpr u32 SPIX_NONE = 0xFFFFFFFFu;  // k_rows -> k_fin: no source in the frame
 constexpr u32 K_IDENT = 0x3FFFFFFFu;  // larger than any real key, small enough to survive the +- (column << 15)
 constexpr int PL_D0 = 0, PL_D1 = 1, PL_D2 = 2, PL_LIVE = 3, PL_TIE = 4, PL_UNRES = 5, PL_N = 6;
 
@@ -171,11 +172,8 @@ constexpr int R_MAXPW = 256;   // 32-pixel words per row: W <= 8191
 
 template <int PPL, int MAXT>  // MAXT: 256 (rows of up to 4 waves; 3 waves per SIMD) or 1024 (any row the shape limit allows)
 __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
-    const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, const u64 *__restrict__ srcbits,
-    const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s, const int *__restrict__ finfo,
-    const float *__restrict__ vlist, const int *__restrict__ fflag, int H, int W, int Wd, int nb, int Wp,
-    u8 *__restrict__ planes, size_t plane_bytes, float *__restrict__ out_depth, float *__restrict__ out_dt,
-    int32_t *__restrict__ out_index, int *__restrict__ frame_status, int ovec) {
+    const uint2 *__restrict__ ct, int CTP, const int *__restrict__ fflag, int H, int W, int nb, int Wp,
+    u8 *__restrict__ planes, size_t plane_bytes, float *__restrict__ out_dt, u32 *__restrict__ spix_out, int ovec) {
     static_assert(PPL == 8 || PPL == 10, "loads and stores below are written for 8 or 10 columns per lane");
     __shared__ u32 s_tot[R_MAXWV][6];
     __shared__ u32 s_bits[5][R_MAXPW + 1];
@@ -197,7 +195,6 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
             T[q] = v.x; UD[q] = v.y; T[q + 1] = v.z; UD[q + 1] = v.w;
         }
     }
-    const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
     const u32 fo = (u32)b * (u32)(H * W);  // < 2^31 (shape_ok)
     __syncthreads();  // s_bits is zero
     // six keys per column: {all sources, prefer the smallest column | all, prefer the largest | sources at or above
@@ -281,9 +278,8 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
 
     // ---- per pixel: distance, nearest source, flags
     float fd[PPL];
-    u32 spix[PPL], wrd[PPL], srow[PPL], scol[PPL];  // the nearest source (kmin's): frame offset, bit word, row, column
+    u32 spix[PPL];  // frame offset of the nearest source in column kmin; SPIX_NONE: the frame has no source
     u32 acc012 = 0, acc34 = 0;  // bit planes of the lane's pixels: plane p of pixel q at bit 10 p + q
-    u32 nonebits = 0;
     const u32 jbase = ((u32)idx0 << K_SH) - ((u32)K_OFF << K_SH);
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
@@ -306,17 +302,13 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
         // bit p of b5 -> bit 10 p + q: copies of the low three / the high two bits at offsets 0, 9, 18 (24-bit multiply)
         acc012 |= (__umul24(b5 & 7u, 0x040201u) & 0x100401u) << q;
         acc34 |= (__umul24(b5 >> 3, 0x000201u) & 0x000401u) << q;
-        nonebits |= none ? 1u << q : 0u;
         fd[q] = none ? 8192.0f : (float)d;  // float(INIT_DIST0 * 2^-16) == 8192.0f
-        // the nearest source in column kmin (for a tie pixel: one of its nearest sources; k_ties overwrites it)
+        // the nearest source in column kmin (for a tie pixel: one of its nearest sources; k_fin takes another pixel's)
         const int gk = (int)d - (int)__builtin_amdgcn_sad_u16((u32)j, kmin, 0u);  // d - |j - kmin| (both < 2^13)
         const int sg = (int)((bmin & 1u) << 1) - 1;                              // below: +1, above: -1
         const int si = min(max(i + sg * gk, 0), H - 1);  // clamps: never taken on a correct frame
         const u32 sj = min(kmin, (u32)(W - 1));
-        srow[q] = (u32)si;
-        scol[q] = sj;
-        spix[q] = (u32)si * (u32)W + sj;
-        wrd[q] = (u32)si * (u32)Wd + (sj >> 6);
+        spix[q] = none ? SPIX_NONE : (u32)si * (u32)W + sj;  // frame offset of the source pixel
     }
     // ---- bit planes: a lane's PPL bits of each plane are ORed into the row's words in LDS
     if (idx0 < W) {
@@ -331,70 +323,26 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
             }
         }
     }
-    // ---- label, depth: all loads of the lane's pixels are issued together
-    int lab[PPL];
-    float fv[PPL];
-    if (out_depth || out_index) {
-        // frame bases are block-uniform (scalar registers); per pixel only 32-bit byte offsets
-        const u64 *sb_f = srcbits + (size_t)b * H * Wd;
-        const u16 *wp_f = wpre_s + (size_t)b * H * Wd;
-        const u32 *rb_f = rowbase_s + (size_t)b * H;
-        const float *x_f = x + fo;
-        u32 base[PPL];
-        u64 word[PPL];
-        bool bad = false;
-#pragma unroll
-        for (int q = 0; q < PPL; ++q) {
-            base[q] = ld_off<u32>(rb_f, srow[q] << 2) + ld_off<u16>(wp_f, wrd[q] << 1);
-            word[q] = ld_off<u64>(sb_f, wrd[q] << 3);
-        }
-        if (!misaligned) {  // block-uniform: the label-th value IS x at the source pixel
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) fv[q] = ld_off<float>(x_f, spix[q] << 2);
-        }
-#pragma unroll
-        for (int q = 0; q < PPL; ++q) {
-            const bool none = (nonebits >> q) & 1u;
-            lab[q] = none ? 0 : source_rank(base[q], word[q], (int)scol[q]);  // a select, not a branch
-        }
-        if (misaligned || nonebits) {  // rare: value list gather with numpy's index rules (tools.py:26)
-#pragma unroll
-            for (int q = 0; q < PPL; ++q) {
-                int idx = lab[q] - 1;
-                if (idx < 0) idx += nval;  // numpy: index -1 wraps to the last element
-                const bool oob = idx < 0 || idx >= nval;
-                bad |= oob && idx0 + q < W;
-                // label 0 with aligned masks: nval == nsrc == 0 -> out of bounds; so an in-bounds gather reads the value list
-                fv[q] = oob ? nanf("") : (misaligned ? vlist[fo + idx] : x_f[spix[q]]);
-            }
-        }
-        if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
-    }
     // ---- stores (frame bases scalar, 32-bit byte offsets)
     const bool full = idx0 + PPL <= W;
     const u32 rob = ((u32)i * (u32)W + (u32)idx0) << 2;
-    float *dt_f = out_dt ? out_dt + fo : nullptr, *dp_f = out_depth ? out_depth + fo : nullptr;
-    int32_t *ix_f = out_index ? out_index + fo : nullptr;
+    float *dt_f = out_dt ? out_dt + fo : nullptr;
+    u32 *sp_f = spix_out ? spix_out + fo : nullptr;
     if (ovec && full) {
         if (PPL == 8) {
             if (dt_f) {
                 st_off(dt_f, rob, make_float4(fd[0], fd[1], fd[2], fd[3]));
                 st_off(dt_f, rob + 16, make_float4(fd[4], fd[5], fd[6], fd[7]));
             }
-            if (ix_f) {
-                st_off(ix_f, rob, make_int4(lab[0], lab[1], lab[2], lab[3]));
-                st_off(ix_f, rob + 16, make_int4(lab[4], lab[5], lab[6], lab[7]));
-            }
-            if (dp_f) {
-                st_off(dp_f, rob, make_float4(fv[0], fv[1], fv[2], fv[3]));
-                st_off(dp_f, rob + 16, make_float4(fv[4], fv[5], fv[6], fv[7]));
+            if (sp_f) {
+                st_off(sp_f, rob, make_uint4(spix[0], spix[1], spix[2], spix[3]));
+                st_off(sp_f, rob + 16, make_uint4(spix[4], spix[5], spix[6], spix[7]));
             }
         } else {
 #pragma unroll
             for (int q = 0; q < PPL; q += 2) {
                 if (dt_f) st_off(dt_f, rob + 4 * q, make_float2(fd[q], fd[q + 1]));
-                if (ix_f) st_off(ix_f, rob + 4 * q, make_int2(lab[q], lab[q + 1]));
-                if (dp_f) st_off(dp_f, rob + 4 * q, make_float2(fv[q], fv[q + 1]));
+                if (sp_f) st_off(sp_f, rob + 4 * q, make_uint2(spix[q], spix[q + 1]));
             }
         }
     } else {
@@ -402,8 +350,7 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
         for (int q = 0; q < PPL; ++q) {
             if (idx0 + q >= W) continue;
             if (dt_f) st_off(dt_f, rob + 4 * q, fd[q]);
-            if (ix_f) st_off(ix_f, rob + 4 * q, lab[q]);
-            if (dp_f) st_off(dp_f, rob + 4 * q, fv[q]);
+            if (sp_f) st_off(sp_f, rob + 4 * q, spix[q]);
         }
     }
     __syncthreads();
@@ -414,19 +361,27 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_ties: one block (256 threads) per 32 x 256 tile, one thread per 32-pixel word of it.  The tile's planes (d mod 8,
-// live, tie) with a 2-cell ring go to LDS once (every plane word is read from memory once per block, in runs of
-// 40 bytes).  A thread whose word holds a tie pixel applies the 5x5 parent rule BIT-SLICED, 32 pixels per
-// operation, on d mod 8: a tap of weight w <= 3 matches iff d(r) + w == d(q), and |d(r) - d(q)| <= w makes that
-// exact mod 8.  The tile's tie pixels, as a list, then hop through the tile's code planes in LDS until they stand
-// on a pixel that is not a tie pixel (one nearest source, or a source) and copy that pixel's label and depth, which
-// k_rows has written.  A chain that leaves the tile while still on tie pixels records where it goes on (xptr[q] =
-// that pixel, and q's bit in the "unresolved" plane, every word of which is written here) and is listed for k_tiesx.
+// k_fin: one block (256 threads) per 32 x 256 tile, one thread per 32-pixel word of it: tie pixels get their source,
+// then every pixel of the tile gets its label and depth, written as whole 128-byte runs (nothing is patched in
+// memory afterwards except the few pixels of k_tiesx).
+//   1. The tile's planes (d mod 8, live, tie) with a 2-cell ring go to LDS once.
+//   2. A thread whose word holds a tie pixel applies the 5x5 parent rule BIT-SLICED, 32 pixels per operation, on
+//      d mod 8: a tap of weight w <= 3 matches iff d(r) + w == d(q), and |d(r) - d(q)| <= w makes that exact mod 8.
+//   3. Its tie pixels hop through the tile's code planes in LDS until they stand on a pixel that is not a tie pixel
+//      (one nearest source, or a source) and take over that pixel's source (k_rows left every pixel's nearest
+//      source in column kmin in spix).  A chain that leaves the tile while still on tie pixels records where it
+//      goes on (xptr, the "unresolved" plane, the frame's list) for k_tiesx.
+//   4. label = 1 + raster rank of the source (cv2's label init), depth = depth_list[label - 1] with numpy's index
+//      rules (tools.py:24-26); three loads + a gather per pixel, eight pixels' worth in flight per thread.
 // ------------------------------------------------------------------------------------------------
 constexpr int Q_TH = 32, Q_TW = 256;
 constexpr int Q_NT = 256;
 constexpr int Q_WW = Q_TW / 32;  // tile words per row
-constexpr int Q_EB = 8;          // list entries per thread whose copies are in flight together
+constexpr u32 P_IDX = 0x1FFFu, P_EXIT = 0x4000u, P_TERM = 0x8000u;  // s_ptr: tile index (row * 256 + column), flags
+constexpr u32 B_MULTI = 0x80u;                                       // s_byte: the pixel's parent is a tie pixel too
+constexpr u32 P_UNRES = 0xFFFFu;                                     // s_ptr, final form: chain goes on in another tile
+constexpr int Q_LW = Q_TW + 64;                                      // s_ptr, final form: (row + 2) * Q_LW + column + 32
+static_assert(Q_TH * Q_TW <= 0x2000 && Q_TW == 256, "s_ptr packs row << 8 | column into 13 bits");
 constexpr int Q_RS = Q_WW + 3;   // LDS row pitch in words: image words c0/32 - 1 .. c0/32 + Q_WW, + 1 (odd: 11)
 static_assert(Q_TH * Q_WW == Q_NT, "one tile word per thread");
 
@@ -459,26 +414,48 @@ __device__ __forceinline__ void rule_tap(const u32 (&a0)[3], const u32 (&a1)[3],
         if (CODE & (1 << j)) C[j] |= sel;
 }
 
-__global__ __launch_bounds__(Q_NT) void k_ties(const u8 *__restrict__ planes, size_t plane_bytes, int Wp,
-                                               const int *__restrict__ fflag, int H, int W, int tiles_x,
-                                               float *out_depth, int32_t *out_index, int *__restrict__ finfo,
-                                               u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres) {
+// the pixels (of 32) whose code planes C spell tap CODE: do they hop onto a tie pixel (T = tie plane of rows -2 .. +2, three
+// words each)?  Their step code (di + 2) << 3 | (dj + 2) goes into the planes E.
+template <int CODE>
+__device__ __forceinline__ void step_tap(const u32 (&C)[4], u32 mytie, const u32 (&T)[5][3], u32 &multi, u32 (&E)[6]) {
+    constexpr int t = CODE & 7;
+    constexpr int DI = (CODE & 8) ? -TAP_DI(t) : TAP_DI(t), DJ = (CODE & 8) ? -TAP_DJ(t) : TAP_DJ(t);
+    u32 sel = mytie;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sel &= (CODE & (1 << j)) ? C[j] : ~C[j];
+    multi |= sel & qshift<DJ>(T[DI + 2]);
+    constexpr int ENC = (DI + 2) << 3 | (DJ + 2);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+        if (ENC & (1 << j)) E[j] |= sel;
+}
+
+__global__ __launch_bounds__(Q_NT, 4) void k_fin(
+    const u8 *__restrict__ planes, size_t plane_bytes, int Wp, const int *__restrict__ fflag, int H, int W, int Wd,
+    int tiles_x, const u32 *__restrict__ spix_ws, const float *__restrict__ x, const int32_t *__restrict__ labelmap,
+    const float *__restrict__ vlist,
+    float *__restrict__ out_depth, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
+    int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres, int vec) {
     __shared__ u32 s_pl[6][Q_TH + 4][Q_RS];  // d bit 0, 1, 2, live, tie, in-image; rows r0-2 .. r0+TH+1
-    __shared__ u32 s_code[4][Q_TH][Q_WW + 1];
-    __shared__ u16 s_list[Q_TH * Q_TW];
+    __shared__ u8 s_byte[Q_TH][Q_TW];   // per tile pixel: step to its parent ((di + 2) << 3 | (dj + 2); 18 = none) | B_MULTI
+    __shared__ u16 s_ptr[Q_TH * Q_TW];  // per tile pixel: an ancestor on its chain (tile index) | P_TERM | P_EXIT
     __shared__ u32 s_cnt[Q_NT / 64];
-    __shared__ u32 s_unres[Q_NT];
     const int b = blockIdx.y, tid = threadIdx.x;
     if (!fflag[b]) return;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * Q_TH, c0 = tx * Q_TW;
     const int wpr = Wp >> 2;  // 32-pixel words per plane row
     const size_t rowb = (size_t)b * H;
+    const u32 fo = (u32)b * (u32)(H * W);
+    const u32 *sp_f = spix_ws + fo;
     // this thread's tile word
     const int trow = tid / Q_WW, tw = tid % Q_WW;
     const int gi = r0 + trow, gw = (c0 >> 5) + tw;  // image row, image word (32 px) column
     const bool tin = gi < H && gw < wpr;            // the word exists in the planes (its pixels beyond W are zero bits)
-    u32 *ures = reinterpret_cast<u32 *>(unres + (rowb + min(gi, H - 1)) * Wp) + gw;
+    // phase 4 mapping: a wave takes tile rows ewave, ewave + waves, ..., a lane four consecutive pixels of the row
+    const int elane = tid & 63, ewave = tid >> 6;
+    const int lw = elane >> 3, lb = (elane & 7) * 4;  // the lane's word in the row, first bit in it
+    const int col = c0 + elane * 4;
     // ---- the window's planes -> LDS: (TH + 4) rows x (WW + 2) words, item = (row, word), all five planes of an item
     // by the same thread (all loads of a thread are issued before its first LDS store)
     {
@@ -508,160 +485,270 @@ __global__ __launch_bounds__(Q_NT) void k_ties(const u8 *__restrict__ planes, si
             }
         }
     }
-    s_unres[tid] = 0;
     __syncthreads();
     const u32 mytie = s_pl[4][trow + 2][tw + 1];
-    if (!__syncthreads_or(mytie != 0)) {  // no tie pixel in this tile
-        if (tin) *ures = 0;
-        return;
-    }
-    // ---- parent rule for this word (planes from LDS: rows trow .. trow + 4 of the window, words tw .. tw + 2)
-    if (mytie) {
-        auto ld3 = [&](int p, int row, u32 (&o)[3]) {
-            const u32 *sp = &s_pl[p][row][tw];
-            o[0] = sp[0]; o[1] = sp[1]; o[2] = sp[2];
-        };
-        const int qrow = trow + 2;
-        const u32 b0 = s_pl[0][qrow][tw + 1], b1 = s_pl[1][qrow][tw + 1], b2 = s_pl[2][qrow][tw + 1];
-        const u32 qlive = s_pl[3][qrow][tw + 1];
-        u32 takenF = ~(mytie & qlive), takenB = ~(mytie & ~qlive);
+    u32 left = 0;  // tie pixels of this word that k_tiesx finishes
+    const bool any_tie = __syncthreads_or(mytie != 0);  // block-uniform: some tie pixel in this tile
+    if (any_tie) {
         u32 C[4] = {0, 0, 0, 0};
-        u32 a0[3], a1[3], a2[3], lv[3], vd[3];
-        // cv2 tap order: (-2,-1) (-2,+1) (-1,-2) (-1,-1) (-1,0) (-1,+1) (-1,+2) (0,-1); backward = the negated offsets in
-        // the same order.  The two chains are independent (live / non-live pixels), each keeps its order.
-        ld3(0, qrow - 2, a0); ld3(1, qrow - 2, a1); ld3(2, qrow - 2, a2); ld3(3, qrow - 2, lv); ld3(5, qrow - 2, vd);
-        rule_tap<-1, 3, true, 0>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
-        rule_tap<+1, 3, true, 1>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
-        ld3(0, qrow - 1, a0); ld3(1, qrow - 1, a1); ld3(2, qrow - 1, a2); ld3(3, qrow - 1, lv); ld3(5, qrow - 1, vd);
-        rule_tap<-2, 3, true, 2>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
-        rule_tap<-1, 2, true, 3>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
-        rule_tap<0, 1, true, 4>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
-        rule_tap<+1, 2, true, 5>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
-        rule_tap<+2, 3, true, 6>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
-        u32 z0[3], z1[3], z2[3], zv[3];  // this row: last forward tap now, last backward tap at the end
-        ld3(0, qrow, z0); ld3(1, qrow, z1); ld3(2, qrow, z2); ld3(3, qrow, lv); ld3(5, qrow, zv);
-        rule_tap<-1, 1, true, 7>(z0, z1, z2, lv, zv, b0, b1, b2, takenF, C);
-        ld3(0, qrow + 2, a0); ld3(1, qrow + 2, a1); ld3(2, qrow + 2, a2); ld3(5, qrow + 2, vd);
-        rule_tap<+1, 3, false, 8 | 0>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
-        rule_tap<-1, 3, false, 8 | 1>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
-        ld3(0, qrow + 1, a0); ld3(1, qrow + 1, a1); ld3(2, qrow + 1, a2); ld3(5, qrow + 1, vd);
-        rule_tap<+2, 3, false, 8 | 2>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
-        rule_tap<+1, 2, false, 8 | 3>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
-        rule_tap<0, 1, false, 8 | 4>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
-        rule_tap<-1, 2, false, 8 | 5>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
-        rule_tap<-2, 3, false, 8 | 6>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
-        rule_tap<+1, 1, false, 8 | 7>(z0, z1, z2, lv, zv, b0, b1, b2, takenB, C);
+        u32 multi = 0;  // tie pixels whose parent is a tie pixel too (the others end their chain after ONE hop)
+        u32 E[6] = {0, ~0u, 0, 0, ~0u, 0};  // bit planes of the step code (di + 2) << 3 | (dj + 2); 18 = (0, 0) where no tie pixel
+        // ---- parent rule for this word (planes from LDS: rows trow .. trow + 4 of the window, words tw .. tw + 2)
+        if (mytie) {
+            auto ld3 = [&](int p, int row, u32 (&o)[3]) {
+                const u32 *q3 = &s_pl[p][row][tw];
+                o[0] = q3[0]; o[1] = q3[1]; o[2] = q3[2];
+            };
+            const int qrow = trow + 2;
+            const u32 b0 = s_pl[0][qrow][tw + 1], b1 = s_pl[1][qrow][tw + 1], b2 = s_pl[2][qrow][tw + 1];
+            const u32 qlive = s_pl[3][qrow][tw + 1];
+            u32 takenF = ~(mytie & qlive), takenB = ~(mytie & ~qlive);
+            u32 a0[3], a1[3], a2[3], lv[3], vd[3];
+            // cv2 tap order: (-2,-1) (-2,+1) (-1,-2) (-1,-1) (-1,0) (-1,+1) (-1,+2) (0,-1); backward = the negated offsets
+            // in the same order.  The two chains are independent (live / non-live pixels), each keeps its order.
+            ld3(0, qrow - 2, a0); ld3(1, qrow - 2, a1); ld3(2, qrow - 2, a2); ld3(3, qrow - 2, lv); ld3(5, qrow - 2, vd);
+            rule_tap<-1, 3, true, 0>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
+            rule_tap<+1, 3, true, 1>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
+            ld3(0, qrow - 1, a0); ld3(1, qrow - 1, a1); ld3(2, qrow - 1, a2); ld3(3, qrow - 1, lv); ld3(5, qrow - 1, vd);
+            rule_tap<-2, 3, true, 2>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
+            rule_tap<-1, 2, true, 3>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
+            rule_tap<0, 1, true, 4>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
+            rule_tap<+1, 2, true, 5>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
+            rule_tap<+2, 3, true, 6>(a0, a1, a2, lv, vd, b0, b1, b2, takenF, C);
+            u32 z0[3], z1[3], z2[3], zv[3];  // this row: last forward tap now, last backward tap at the end
+            ld3(0, qrow, z0); ld3(1, qrow, z1); ld3(2, qrow, z2); ld3(3, qrow, lv); ld3(5, qrow, zv);
+            rule_tap<-1, 1, true, 7>(z0, z1, z2, lv, zv, b0, b1, b2, takenF, C);
+            ld3(0, qrow + 2, a0); ld3(1, qrow + 2, a1); ld3(2, qrow + 2, a2); ld3(5, qrow + 2, vd);
+            rule_tap<+1, 3, false, 8 | 0>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
+            rule_tap<-1, 3, false, 8 | 1>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
+            ld3(0, qrow + 1, a0); ld3(1, qrow + 1, a1); ld3(2, qrow + 1, a2); ld3(5, qrow + 1, vd);
+            rule_tap<+2, 3, false, 8 | 2>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
+            rule_tap<+1, 2, false, 8 | 3>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
+            rule_tap<0, 1, false, 8 | 4>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
+            rule_tap<-1, 2, false, 8 | 5>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
+            rule_tap<-2, 3, false, 8 | 6>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
+            rule_tap<+1, 1, false, 8 | 7>(z0, z1, z2, lv, zv, b0, b1, b2, takenB, C);
+            // which tie pixels hop onto another tie pixel, and every tie pixel's step code, still bit-sliced: tap t was
+            // chosen where the code planes spell t
+            {
+                u32 T[5][3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s_code[j][trow][tw] = C[j];
-    }
-    // ---- the tile's tie pixels as a list (tile row << 8 | tile column), so that the hops are spread evenly
-    int n_all;
-    {
-        const int cnt = __popc(mytie);
-        int incl = cnt;
-        const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) s_cnt[wave] = (u32)incl;
-        __syncthreads();  // also: s_code is complete
-        int pre = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w < Q_NT / 64; ++w) {
-            pre += w < wave ? (int)s_cnt[w] : 0;
-            all += (int)s_cnt[w];
-        }
-        n_all = all;
-        int o = pre + incl - cnt;
-        u32 m = mytie;
-        while (m) {
-            const int bit = __ffs((int)m) - 1;
-            m &= m - 1;
-            s_list[o++] = (u16)(trow << 8 | (tw * 32 + bit));
-        }
-    }
-    __syncthreads();
-    // ---- hops inside the tile, Q_EB list entries per thread at a time: first all the hops (LDS only), then all the
-    // copies (independent loads), then the stores.
-    // reads: pixels that are NOT tie pixels; writes: tie pixels -- the two sets never meet inside this kernel
-    const int32_t *__restrict__ rd_i = out_index;
-    const float *__restrict__ rd_f = out_depth;
-    int32_t *__restrict__ wr_i = out_index;
-    float *__restrict__ wr_f = out_depth;
-    const size_t fo = (size_t)b * H * W;
-    for (int e0 = 0; e0 < n_all; e0 += Q_EB * Q_NT) {  // block-uniform trip count
-        int qoff[Q_EB], poff[Q_EB];
-        u32 okm = 0, givem = 0;
-#pragma unroll
-        for (int u = 0; u < Q_EB; ++u) {
-            const int e = e0 + u * Q_NT + tid;
-            const bool have = e < n_all;
-            bool solved = false;
-            const int start = have ? (int)s_list[e] : 0;
-            int r = start >> 8, c = start & 255;  // tile coordinates
-            for (int hop = 0; have && hop < Q_TH + Q_TW; ++hop) {  // d falls with every hop: the bound is never reached
-                const int w = c >> 5, bt = c & 31;
-                const int code = (int)((s_code[0][r][w] >> bt) & 1u) | (int)((s_code[1][r][w] >> bt) & 1u) << 1 |
-                                 (int)((s_code[2][r][w] >> bt) & 1u) << 2 | (int)((s_code[3][r][w] >> bt) & 1u) << 3;
-                int di, dj;
-                tap_decode(code, di, dj);
-                r += di;
-                c += dj;
-                if (!((s_pl[4][r + 2][(c + 32) >> 5] >> ((c + 32) & 31)) & 1u)) {  // not a tie pixel: its label is the chain's
-                    solved = true;
-                    break;
-                }
-                if (r < 0 || r >= Q_TH || c < 0 || c >= Q_TW) break;  // a tie pixel of another tile: no code here
+                for (int dr = 0; dr < 5; ++dr) ld3(4, trow + dr, T[dr]);
+                E[1] = E[4] = ~mytie;
+                step_tap<0>(C, mytie, T, multi, E);
+                step_tap<1>(C, mytie, T, multi, E);
+                step_tap<2>(C, mytie, T, multi, E);
+                step_tap<3>(C, mytie, T, multi, E);
+                step_tap<4>(C, mytie, T, multi, E);
+                step_tap<5>(C, mytie, T, multi, E);
+                step_tap<6>(C, mytie, T, multi, E);
+                step_tap<7>(C, mytie, T, multi, E);
+                step_tap<8>(C, mytie, T, multi, E);
+                step_tap<9>(C, mytie, T, multi, E);
+                step_tap<10>(C, mytie, T, multi, E);
+                step_tap<11>(C, mytie, T, multi, E);
+                step_tap<12>(C, mytie, T, multi, E);
+                step_tap<13>(C, mytie, T, multi, E);
+                step_tap<14>(C, mytie, T, multi, E);
+                step_tap<15>(C, mytie, T, multi, E);
             }
-            const int ei = min(max(r0 + r, 0), H - 1), ej = min(max(c0 + c, 0), W - 1);  // inside the image on consistent planes
-            qoff[u] = have ? (r0 + (start >> 8)) * W + c0 + (start & 255) : 0;
-            poff[u] = have ? ei * W + ej : 0;
-            okm |= (have && solved) ? 1u << u : 0u;
-            givem |= (have && !solved) ? 1u << u : 0u;
-            if (have && !solved) atomicOr(&s_unres[(start >> 8) * Q_WW + ((start & 255) >> 5)], 1u << (start & 31));
         }
-        if (out_index) {
-            int32_t v[Q_EB];
+        // un-slice into one byte per pixel, four pixels per step: ((nibble * 0x00204081) & 0x01010101) spreads a nibble's
+        // bits to the low bits of four bytes (24-bit multiplies)
+        {
+            u32 *brow = reinterpret_cast<u32 *>(&s_byte[trow][tw * 32]);
 #pragma unroll
-            for (int u = 0; u < Q_EB; ++u) v[u] = rd_i[fo + poff[u]];
+            for (int g = 0; g < 8; ++g) {
+                u32 v = 0;
 #pragma unroll
-            for (int u = 0; u < Q_EB; ++u)
-                if ((okm >> u) & 1u) wr_i[fo + qoff[u]] = v[u];
+                for (int j = 0; j < 6; ++j) v |= (mul_u24_opaque((E[j] >> (4 * g)) & 0xFu, 0x00204081u) & 0x01010101u) << j;
+                v |= (mul_u24_opaque((multi >> (4 * g)) & 0xFu, 0x00204081u) & 0x01010101u) << 7;  // B_MULTI
+                brow[g] = v;
+            }
         }
-        if (out_depth) {
-            float v[Q_EB];
-#pragma unroll
-            for (int u = 0; u < Q_EB; ++u) v[u] = rd_f[fo + poff[u]];
-#pragma unroll
-            for (int u = 0; u < Q_EB; ++u)
-                if ((okm >> u) & 1u) wr_f[fo + qoff[u]] = v[u];
+        __syncthreads();
+        // ---- the few chains of more than one hop: pointer doubling over the "multi" pixels (any chain length in a few
+        // rounds; a pixel's ancestors are shared by every chain through it).  s_ptr[q] = a pixel further along q's chain;
+        // P_TERM: that pixel is the last tie pixel of the chain inside this tile -- one hop from it ends the chain
+        // (not a tie pixel) or (P_EXIT) leaves the tile onto another tie pixel.
+        {
+            const int qb = trow * Q_TW + tw * 32;
+            const u8 *bflat = &s_byte[0][0];
+            u32 open = 0, m = multi;
+            while (m) {
+                const int k = __ffs((int)m) - 1;
+                m &= m - 1;
+                const int st = bflat[qb + k] & 63;
+                const int pr = trow + (st >> 3) - 2, pc = tw * 32 + k + (st & 7) - 2;
+                u32 v;
+                if (pr < 0 || pr >= Q_TH || pc < 0 || pc >= Q_TW) {
+                    v = (u32)(qb + k) | P_TERM | P_EXIT;
+                } else {
+                    const bool pm = bflat[pr * Q_TW + pc] & B_MULTI;
+                    v = (u32)(pr * Q_TW + pc) | (pm ? 0u : P_TERM);
+                    open |= pm ? 1u << k : 0u;
+                }
+                s_ptr[qb + k] = (u16)v;
+            }
+            __syncthreads();
+            // doubling: any value read is an ancestor (other threads only ever replace a pointer by a farther ancestor)
+            for (int round = 0; round < 16; ++round) {  // 2^16 > any chain inside a tile
+                u32 mm = open;
+                while (mm) {
+                    const int k = __ffs((int)mm) - 1;
+                    mm &= mm - 1;
+                    const u32 a = s_ptr[qb + k];  // no flag: q is open
+                    const u32 pa = s_ptr[a & P_IDX];
+                    s_ptr[qb + k] = (u16)pa;
+                    if (pa & P_TERM) open &= ~(1u << k);
+                }
+                if (!__syncthreads_or(open != 0)) break;
+            }
+            // one hop from the last tie pixel: s_ptr[q] becomes the window position of the pixel whose source q takes
+            // ((row + 2) * Q_LW + column + 32), or P_UNRES if the chain goes on in another tile: q is listed for k_tiesx
+            // with the pixel where it goes on.
+            m = multi;
+            while (m) {
+                const int k = __ffs((int)m) - 1;
+                m &= m - 1;
+                const u32 t = s_ptr[qb + k];
+                const int cr = (int)((t & P_IDX) >> 8), cc = (int)(t & 255u);  // Q_TW == 256
+                const int st = bflat[(t & P_IDX)] & 63;
+                const int er = cr + (st >> 3) - 2, ec = cc + (st & 7) - 2;
+                const bool solved = !(t & P_EXIT);
+                s_ptr[qb + k] = solved ? (u16)((er + 2) * Q_LW + ec + 32) : (u16)P_UNRES;
+                if (!solved) {
+                    const int ei = min(max(r0 + er, 0), H - 1), ej = min(max(c0 + ec, 0), W - 1);  // in the image on consistent planes
+                    left |= 1u << k;
+                    xptr[fo + (u32)(gi * W + gw * 32 + k)] = (u32)(ei * W + ej);
+                }
+            }
         }
-        // the others go on in another tile: k_tiesx follows them from (ei, ej).  One slot of the frame's list per pixel,
-        // one atomic per wave.
-        if (__any(givem != 0)) {
-            const int lane = tid & 63;
-            const int cnt = __popc(givem);
-            int incl = cnt;
+        // the handed-on pixels join the frame's list: block-wide count, ONE atomic, then every thread writes its own
+        {
+            const int cu = __popc(left);
+            int incl = cu;
+            const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const int t = __shfl_up(incl, off);
                 if (lane >= off) incl += t;
             }
-            int base = 0;
-            if (lane == 63) base = atomicAdd(&finfo[b * FI_STRIDE + FI_NUNRES], incl);
-            int o = __shfl(base, 63) + incl - cnt;
+            if (lane == 63) s_cnt[wave] = (u32)incl;
+            __syncthreads();  // also: s_ptr holds the final positions
+            int pre = 0, all = 0;
 #pragma unroll
-            for (int u = 0; u < Q_EB; ++u)
-                if ((givem >> u) & 1u) {
-                    xptr[fo + qoff[u]] = (u32)poff[u];
-                    xlist[fo + o++] = (u32)qoff[u];
+            for (int w = 0; w < Q_NT / 64; ++w) {
+                pre += w < wave ? (int)s_cnt[w] : 0;
+                all += (int)s_cnt[w];
+            }
+            if (all) {  // block-uniform
+                __syncthreads();
+                if (tid == 0) s_cnt[0] = (u32)atomicAdd(&finfo[b * FI_STRIDE + FI_NUNRES], all);
+                __syncthreads();
+                u32 o = s_cnt[0] + (u32)(pre + incl - cu);
+                u32 mm = left;
+                while (mm) {
+                    const int k = __ffs((int)mm) - 1;
+                    mm &= mm - 1;
+                    xlist[fo + o++] = (u32)(gi * W + gw * 32 + k);
                 }
+            }
         }
     }
-    __syncthreads();
-    if (tin) *ures = s_unres[tid];
+    if (tin) reinterpret_cast<u32 *>(unres + (rowb + gi) * Wp)[gw] = left;
+    // ---- 4. label, depth, stores.  A wave takes one tile row at a time, a lane four consecutive pixels of it: every
+    // load of spix and every store is a run of 1 KB per wave.
+    const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
+    const float *x_f = x + fo, *vl_f = vlist + fo;
+    const int32_t *lm_f = labelmap + fo;
+    float *dp_f = out_depth ? out_depth + fo : nullptr;
+    int32_t *ix_f = out_index ? out_index + fo : nullptr;
+    const u32 lastpix = (u32)(H * W - 1);
+    bool bad = false;
+    constexpr int NRW = Q_TH / (Q_NT / 64);  // rows per wave (8)
+    // every pixel takes the source k_rows found for the pixel one step along its chain (step (0, 0) unless it is a tie
+    // pixel); the few tie pixels with longer chains take it from the position s_ptr holds
+    u32 esp[NRW][4];
+#pragma unroll
+    for (int it = 0; it < NRW; ++it) {
+        const int rr = ewave + (Q_NT / 64) * it;
+        const int i = r0 + rr;
+        const u32 inm = (s_pl[5][rr + 2][lw + 1] >> lb) & 15u;
+        const u32 b4 = any_tie ? *reinterpret_cast<const u32 *>(&s_byte[rr][elane * 4]) : 0x12121212u;
+        int pi[4], pj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 bb = (b4 >> (8 * u)) & 0xFFu;
+            pi[u] = i + (int)((bb >> 3) & 7u) - 2;
+            pj[u] = col + u + (int)(bb & 7u) - 2;
+        }
+        if (b4 & 0x80808080u) {  // rare: a chain of more than one hop
+            const uint2 t4 = *reinterpret_cast<const uint2 *>(&s_ptr[rr * Q_TW + elane * 4]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!((b4 >> (8 * u + 7)) & 1u)) continue;
+                const u32 t = ((u & 2) ? t4.y : t4.x) >> (16 * (u & 1)) & 0xFFFFu;
+                const int wr = (int)(t / Q_LW), wc = (int)(t - (u32)wr * Q_LW);  // window position (a constant division)
+                pi[u] = t == P_UNRES ? i : r0 - 2 + wr;  // handed on: keeps k_rows' source until k_tiesx overwrites it
+                pj[u] = t == P_UNRES ? col + u : c0 - 32 + wc;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 off = (u32)(min(max(pi[u], 0), H - 1) * W + min(max(pj[u], 0), W - 1));
+            esp[it][u] = ((inm >> u) & 1u) ? ld_off<u32>(sp_f, off << 2) : SPIX_NONE;
+        }
+    }
+    // label = labelmap[source], depth = depth_list[label - 1] = x[source] when the masks agree: two gathers per pixel,
+    // all 32 pixels of the lane in flight together
+    int lab[NRW][4];
+    float val[NRW][4];
+    u32 nonem = 0;
+#pragma unroll
+    for (int it = 0; it < NRW; ++it)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 v = esp[it][u];
+            const bool none = v == SPIX_NONE;
+            nonem |= none ? 1u << (4 * it + u) : 0u;
+            const u32 off = (none ? 0u : min(v, lastpix)) << 2;
+            lab[it][u] = ix_f || misaligned ? ld_off<int32_t>(lm_f, off) : 0;
+            val[it][u] = dp_f ? ld_off<float>(x_f, off) : 0.0f;
+        }
+#pragma unroll
+    for (int it = 0; it < NRW; ++it) {
+        const int rr = ewave + (Q_NT / 64) * it;
+        const u32 inm = (s_pl[5][rr + 2][lw + 1] >> lb) & 15u;  // in-image bits of the four pixels
+        const u32 pixb = ((u32)min(r0 + rr, H - 1) * (u32)W + (u32)col) << 2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lab[it][u] = ((nonem >> (4 * it + u)) & 1u) ? 0 : lab[it][u];
+        if (dp_f && (misaligned || ((nonem >> (4 * it)) & 15u))) {  // rare: numpy's index rules (tools.py:26)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool none = (nonem >> (4 * it + u)) & 1u;
+                int idx = lab[it][u] - 1;
+                if (idx < 0) idx += nval;  // numpy: index -1 wraps to the last element
+                const bool oob = idx < 0 || idx >= nval;
+                bad |= oob && ((inm >> u) & 1u);
+                // label 0 with agreeing masks means nval == nsrc == 0: out of bounds; so an in-bounds gather of a
+                // source-less frame reads the value list
+                val[it][u] = oob ? nanf("") : ((misaligned || none) ? vl_f[idx] : val[it][u]);
+            }
+        }
+        if (vec && inm == 15u) {
+            if (ix_f) st_off(ix_f, pixb, make_int4(lab[it][0], lab[it][1], lab[it][2], lab[it][3]));
+            if (dp_f) st_off(dp_f, pixb, make_float4(val[it][0], val[it][1], val[it][2], val[it][3]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!((inm >> u) & 1u)) continue;
+                if (ix_f) st_off(ix_f, pixb + 4 * u, lab[it][u]);
+                if (dp_f) st_off(dp_f, pixb + 4 * u, val[it][u]);
+            }
+        }
+    }
+    if (bad) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,12 +1,28 @@
-"""Multi-GPU: frames are independent, so a batch shards contiguously over ranks and the result is
-gathered on the host.  One process per GPU (torch.distributed); no data-path collective on the
-device -- the numpy-out contract of the reference (tools.py:13-35 returns a host array) means an
-RCCL all-gather over xGMI would move bytes that have to cross PCIe to the host anyway.
+"""Multi-GPU: frames are independent, so a batch shards contiguously over ranks (one process per GPU) and
+the result lands in ONE host buffer.  No data-path collective: the numpy-out contract of the reference
+(tools.py:13-35 returns a host array) means an RCCL all-gather over xGMI would move bytes that have to cross
+PCIe to the host anyway.
 
-The gather itself uses torch.distributed on HOST tensors (gloo), so the same code is exercised by
-the world_size-2 CPU tests in tests/test_sharding.py.
+Host gather = every rank's device-to-host copy goes straight into ITS slice of one shared host slab:
+  * the slab is a POSIX shared-memory segment per output (depth, dt, index, status) that rank 0 of the group
+    creates and the other ranks attach to by name (the name travels over the group's store as a broadcast);
+  * every rank pins its mapping with cudaHostRegister when a GPU is present, so the copy is one asynchronous
+    DMA from the rank's GPU into the final place -- no staging buffer, no concatenation, no TCP;
+  * one barrier later the whole batch is in the slab on every rank (same physical pages).
+torch.distributed is used for control only (slab names, the barrier, the error flag), so the world_size-2 gloo
+tests in tests/test_sharding.py exercise exactly this code on the CPU.
+
+Errors: the reference raises IndexError once for the whole batch (tools.py:26).  Here every rank finishes its
+shard, records a per-frame status in the slab, joins the barrier, and then EVERY rank raises the same IndexError
+for the first bad global frame -- no rank is left waiting in a collective.
 """
+import os
+from multiprocessing import shared_memory
+
 import numpy as np
+
+_DTYPES = {"depth": np.float32, "dt": np.float32, "index": np.int32, "status": np.int32}
+FRAME_INDEX_ERROR = 1
 
 
 def shard_range(n_frames, rank, world_size):
@@ -19,65 +35,163 @@ def shard_range(n_frames, rank, world_size):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def gather_frames(local, n_frames, group=None, dst=None):
-    """Host-side gather of per-rank frame slabs into one [n_frames, ...] array.
-
-    local: numpy array [hi-lo, ...] for this rank's shard_range.  With dst=None every rank gets the
-    full array (all_gather); otherwise only rank `dst` does and the others return None."""
-    import torch
+def _dist(group):
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()):
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(group), dist.get_world_size(group)
+    return None, 0, 1
+
+
+class HostSlab:
+    """One host buffer [n_frames, ...] per output name, shared by the ranks of a group.
+
+    Rank 0 creates the segments, the others attach; `arrays[name]` is a numpy view of the whole batch and
+    `tensors[name]` the torch view of the same memory (pinned when a GPU is present, for async D2H)."""
+
+    def __init__(self, n_frames, frame_shape, names, group=None, pin=None):
+        import torch
+
+        dist, rank, world = _dist(group)
+        self.group, self.rank, self.world = group, rank, world
+        self.names = tuple(names) + ("status",)
+        shapes = {k: ((n_frames,) if k == "status" else (n_frames,) + tuple(frame_shape)) for k in self.names}
+        sizes = {k: max(int(np.prod(shapes[k])) * np.dtype(_DTYPES[k]).itemsize, 1) for k in self.names}
+        self._shm = {}
+        if rank == 0:
+            for k in self.names:
+                self._shm[k] = shared_memory.SharedMemory(create=True, size=sizes[k])
+        if dist is not None:
+            box = [{k: s.name for k, s in self._shm.items()}] if rank == 0 else [None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            if rank != 0:
+                for k in self.names:
+                    self._shm[k] = shared_memory.SharedMemory(name=box[0][k])
+        self.arrays, self.tensors, self._registered = {}, {}, []
+        if pin is None:
+            pin = torch.cuda.is_available()
+        for k in self.names:
+            a = np.ndarray(shapes[k], dtype=_DTYPES[k], buffer=self._shm[k].buf)
+            self.arrays[k] = a
+            t = torch.from_numpy(a)
+            if pin and a.nbytes:
+                # page-lock this process's mapping of the segment: the D2H copy becomes a DMA into the final place
+                rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), a.nbytes, 0)
+                if int(rc) == 0:
+                    self._registered.append(t.data_ptr())
+            self.tensors[k] = t
+
+    def barrier(self):
+        dist, _, _ = _dist(self.group)
+        if dist is not None:
+            dist.barrier(group=self.group)
+
+    def close(self):
+        """Every rank: unpin and unmap.  Rank 0 also removes the segments (call after the last reader is done)."""
+        import torch
+
+        for p in self._registered:
+            torch.cuda.cudart().cudaHostUnregister(p)
+        self._registered = []
+        self.arrays, self.tensors = {}, {}
+        self.barrier()  # nobody unlinks while another rank still reads
+        for s in self._shm.values():
+            s.close()
+            if self.rank == 0:
+                s.unlink()
+        self._shm = {}
+
+
+def gather_frames(local, n_frames, group=None, dst=None):
+    """Host-side gather of per-rank frame slabs into one [n_frames, ...] array through a shared slab.
+
+    local: numpy array [hi-lo, ...] for this rank's shard_range.  With dst=None every rank gets the
+    full array; otherwise only rank `dst` does and the others return None."""
+    dist, rank, world = _dist(group)
+    if dist is None:
         if local.shape[0] != n_frames:
             raise ValueError("single process: local must hold all frames")
         return local
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    tail = local.shape[1:]
-    sizes = [shard_range(n_frames, r, world) for r in range(world)]
-    lo, hi = sizes[rank]
+    lo, hi = shard_range(n_frames, rank, world)
     if local.shape[0] != hi - lo:
         raise ValueError("rank %d: expected %d frames, got %d" % (rank, hi - lo, local.shape[0]))
-    # collectives want equal-sized slabs: pad every shard to the largest one (they differ by at
-    # most one frame) and trim after the gather
-    cap = max(b - a for a, b in sizes)
-    mine = torch.zeros((cap,) + tail, dtype=torch.from_numpy(local[:0]).dtype)
-    mine[: hi - lo] = torch.from_numpy(np.ascontiguousarray(local))
-    bufs = [torch.empty_like(mine) for _ in sizes]
-    if dst is None:
-        dist.all_gather(bufs, mine, group=group)
-    else:
-        dist.gather(mine, bufs if rank == dst else None, dst=dst, group=group)
-        if rank != dst:
-            return None
-    return torch.cat([buf[: b - a] for buf, (a, b) in zip(bufs, sizes)], dim=0).numpy()
+    name = "index" if local.dtype == np.int32 else "depth"
+    slab = HostSlab(n_frames, local.shape[1:], (name,), group=group, pin=False)
+    slab.arrays[name][lo:hi] = local
+    slab.barrier()
+    out = slab.arrays[name].copy() if (dst is None or rank == dst) else None
+    slab.close()
+    return out
+
+
+def select_device(local_rank=None):
+    """One process per GPU: rank r of the node computes on cuda:(LOCAL_RANK % device_count)."""
+    import torch
+
+    if not torch.cuda.is_available():
+        return None
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
+    return torch.device("cuda", dev)
 
 
 def fill_sharded(x, src_thr=0.1, val_thr=0.1, metric="l1_cv", want=("depth", "dt", "index"),
-                 group=None, dst=None, compute=None):
-    """Every rank passes the same full batch x [B,H,W] (or at least its own shard's rows valid);
-    each computes frames shard_range(B, rank, world) on its own GPU and the results are gathered on
-    the host.  `compute(x_shard, src_thr, val_thr, want) -> dict` defaults to the HIP operator on
-    the rank's current device; tests inject a checker there."""
-    import torch.distributed as dist
+                 group=None, dst=None, compute=None, timings=None):
+    """Every rank passes the same full batch x [B,H,W] (or at least its own shard's frames valid); each computes
+    frames shard_range(B, rank, world) on its own GPU (LOCAL_RANK picks it) and copies the results from the device
+    straight into its slice of the shared host slab.  Returns dict name -> [B,H,W] array on every rank (dst=None)
+    or only on rank `dst` (None elsewhere).  Raises IndexError on EVERY rank if any frame of the batch hits
+    numpy's IndexError in depth_list[label_list-1] (tools.py:26) and depth is wanted.
 
-    B = x.shape[0]
-    if dist.is_available() and dist.is_initialized():
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-    else:
-        rank, world = 0, 1
+    compute(x_shard, src_thr, val_thr, want) -> dict of numpy arrays (plus optional "status") replaces the HIP
+    operator; tests inject a checker there.  timings: optional dict that receives "compute_ms" / "gather_ms"."""
+    import time
+
+    B, H, W = x.shape
+    dist, rank, world = _dist(group)
     lo, hi = shard_range(B, rank, world)
-    if compute is None:
-        from . import device as _device
+    slab = HostSlab(B, (H, W), want, group=group)
+    t0 = time.perf_counter()
+    bad, out = (), None
+    try:
+        if compute is None:
+            import torch
 
-        op = _device.default_op(metric)
-        compute = lambda xs, s, v, w: op.run_numpy(xs, s, v, w)
-    if hi > lo:
-        local = compute(np.ascontiguousarray(x[lo:hi]), src_thr, val_thr, want)
-    else:
-        H, W = x.shape[1:]
-        local = {k: np.empty((0, H, W), np.int32 if k == "index" else np.float32) for k in want}
-    out = {}
-    for k in want:
-        out[k] = gather_frames(local[k], B, group=group, dst=dst)
+            from . import device as _device
+
+            dev = select_device()
+            op = _device.default_op(metric)
+            if hi > lo:
+                xd = torch.from_numpy(np.ascontiguousarray(x[lo:hi], dtype=np.float32)).to(dev, non_blocking=False)
+                res = op.run(xd, src_thr, val_thr, want)
+                t1 = time.perf_counter()
+                for k in slab.names:  # device -> this rank's slice of the slab, asynchronously, all outputs in flight
+                    slab.tensors[k][lo:hi].copy_(res[k], non_blocking=True)
+                torch.cuda.current_stream(dev).synchronize()
+            else:
+                t1 = time.perf_counter()
+        else:
+            if hi > lo:
+                local = compute(np.ascontiguousarray(x[lo:hi]), src_thr, val_thr, want)
+                t1 = time.perf_counter()
+                for k in want:
+                    slab.arrays[k][lo:hi] = local[k]
+                slab.arrays["status"][lo:hi] = local.get("status", 0)
+            else:
+                t1 = time.perf_counter()
+        slab.barrier()  # the whole batch is in the slab
+        t2 = time.perf_counter()
+        if timings is not None:
+            timings["compute_ms"] = 1e3 * (t1 - t0)
+            timings["gather_ms"] = 1e3 * (t2 - t1)
+        bad = np.nonzero(slab.arrays["status"] & FRAME_INDEX_ERROR)[0] if "depth" in want else ()
+        if len(bad) == 0 and (dst is None or rank == dst):
+            out = {k: slab.arrays[k].copy() for k in want}  # fresh arrays, as the reference returns
+    finally:
+        slab.close()
+    if len(bad):
+        raise IndexError("frame %d: index out of bounds in depth_list[label_list-1] "
+                         "(value list shorter than a label, or empty with label 0)" % int(bad[0]))
     return out

@@ -41,8 +41,8 @@ def _worker(rank, world, port, n_frames, q):
     x = np.where(rng.random((n_frames, 24, 40)) < 0.06, rng.uniform(1, 80, (n_frames, 24, 40)), 0).astype(np.float32)
 
     def compute(xs, st, vt, want):
-        depth, dt, idx, _ = O.fill_batch(xs, st, vt)
-        return {"depth": depth, "dt": dt, "index": idx}
+        depth, dt, idx, status = O.fill_batch(xs, st, vt)
+        return {"depth": depth, "dt": dt, "index": idx, "status": status}
 
     full = pkg.fill_sharded(x, compute=compute)  # all_gather form
     root_only = pkg.fill_sharded(x, compute=compute, dst=0)
@@ -52,6 +52,17 @@ def _worker(rank, world, port, n_frames, q):
         ok = ok and np.array_equal(root_only["index"], idx)
     else:
         ok = ok and root_only["index"] is None
+    # a frame that makes numpy raise IndexError (no source, empty value list) in the LAST rank's shard: every rank must
+    # raise, none may hang in a collective (the reference raises once for the whole batch, tools.py:26)
+    xb = x.copy()
+    xb[n_frames - 1] = 0
+    try:
+        pkg.fill_sharded(xb, compute=compute)
+        ok = False
+    except IndexError as e:
+        ok = ok and ("frame %d" % (n_frames - 1)) in str(e)
+    only_dt = pkg.fill_sharded(xb, compute=compute, want=("dt",))  # no depth wanted: no error, as in the reference's nearest_point
+    ok = ok and np.array_equal(only_dt["dt"], O.fill_batch(xb)[1])
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
