@@ -6,41 +6,45 @@ B=32 synthetic KITTI-shaped frames per GPU (BASELINE.json configs[1]; 5 % valid 
 KITTI's k/256 grid), inputs resident in HBM before the timed region, all three outputs (filled
 depth, distance map, NN index map) written to HBM.  N>1: one process per GPU, each with its own 32
 frames (frames are independent: no data-path collective; "scaling": "weak"), timing bracketed by a
-barrier + synchronize, MAX over ranks.
+barrier + synchronize, MAX over ranks.  `python bench.py --gpus N` without a launcher starts the N
+ranks itself (torch.distributed.run as a child process, before this process touches a GPU).
 
 Prints ONE JSON line on rank 0, with
   roofline      the slowest kernel of the pass, timed with HIP events on the launch stream:
-                achieved = 16 B/pixel x pixels per launch / its mean duration, vs 8 TB/s HBM peak
+                achieved = 16 B/pixel x pixels per launch / its mean duration, vs 8 TB/s HBM peak;
+                traffic = HBM bytes per launch of that kernel from the committed rocprofv3 PMC
+                passes (profiles/traffic.json, keyed by workload)
   cpu_baseline  the CPU restatement of the reference path (oracle/, kind "port") timed on this
-                box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
+                box's host cores on a bounded sample of the same workload (rank 0, N=1 only):
+                all cores (value) and one thread (single_thread)
+  workloads     (N=1) the other single-GPU configurations of BASELINE.json through the same code:
+                scan-line KITTI (LiDAR-like: empty sky, ring rows), NYU 480x640 B=64 (config 4),
+                2048^2 1 % B=16 (the per-GPU share of config 5), each with its own roofline
+  repeat        the timed loop repeated (median / min / max of ms per step)
+  end_to_end    what a reference-style caller sees: numpy in / numpy out through
+                DT_complete_batch, PCIe included (never `value`)
+  sharded       (N>1, or --sharded) fill_sharded: per-rank D2H straight into one shared pinned
+                host slab; compute and gather time
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 PKG = "distancetransform-depthcompletion_amd"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_PIXEL = 16   # SURVEY 8(d): read f32 depth, write f32 depth + f32 distance + i32 index
+EXTRA_WORKLOADS = ("kitti_b32_scanline", "nyu_b64", "synth2048_b16")
 
 
-def cpu_baseline(x, cpu_seconds=20.0):
-    """Oracle (CPU port of the reference path) over frames of x, one frame per task on a thread
-    pool over all host cores (ctypes releases the GIL; OpenCV's labels transform is serial per
-    frame, so frames are the unit of parallelism)."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as O
-
-    O.lib()
-    # threads = the CPUs this process may actually use (affinity / cgroup quota), not every core of the host
+def host_cores():
+    """CPUs this process may actually use (affinity / cgroup quota), not every core of the host."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -48,12 +52,29 @@ def cpu_baseline(x, cpu_seconds=20.0):
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    cores = min(cores, 64)
+    return min(cores, 64)
+
+
+def cpu_baseline(x, cpu_seconds=20.0):
+    """Oracle (CPU port of the reference path) over frames of x: one frame per task on a thread pool over
+    all host cores (ctypes releases the GIL; OpenCV's labels transform is serial per frame, so frames are
+    the unit of parallelism), and on one thread."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+
+    O.lib()
+    cores = host_cores()
     B = x.shape[0]
     t0 = time.perf_counter()
     O.fill_batch(x[:1])
     per_frame = time.perf_counter() - t0
-    n = int(max(cores, cpu_seconds / max(per_frame, 1e-4)))  # ~cpu_seconds of single-core work in total
+    # one thread: ~a third of the budget
+    n1 = int(max(2, cpu_seconds / 3 / max(per_frame, 1e-4)))
+    t0 = time.perf_counter()
+    for i in range(n1):
+        O.fill_batch(x[i % B : i % B + 1])
+    dt1 = time.perf_counter() - t0
+    n = int(max(cores, cpu_seconds * 2 / 3 / max(per_frame, 1e-4) * min(cores, 4)))
     frames = [x[i % B : i % B + 1] for i in range(n)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
@@ -61,9 +82,76 @@ def cpu_baseline(x, cpu_seconds=20.0):
     dt = time.perf_counter() - t0
     return {
         "value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-        "sample": "%d frames 352x1216 (the bench batch, cycled), C restatement of cv2 L1/5x5 labels "
-                  "transform + tools.py glue, one frame per thread, %d threads, %.1f s" % (n, cores, dt),
+        "single_thread": round(n1 / dt1, 2),
+        "sample": "%d frames %dx%d (the bench batch, cycled), C restatement of cv2 L1/5x5 labels transform + "
+                  "tools.py glue, one frame per thread, %d threads, %.1f s; single_thread: %d frames, %.1f s"
+                  % (n, x.shape[1], x.shape[2], cores, dt, n1, dt1),
     }
+
+
+def load_traffic():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, workload=None, traffic=None):
+    """W untimed passes, then exactly `steps` timed ones between barrier + synchronize; per-kernel HIP-event
+    times from a few instrumented passes.  Returns (line fields, roofline dict)."""
+    B, H, W = x.shape
+    for _ in range(warmup):
+        op.run(x, path=path)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        op.run(x, path=path)
+    barrier()
+    elapsed = reduce_max(time.perf_counter() - t0)
+    rep = []
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            op.run(x, path=path)
+        barrier()
+        rep.append(1e3 * reduce_max(time.perf_counter() - t0) / steps)
+    acc = {}
+    reps = 10
+    for _ in range(reps):
+        op.run(x, timed=True, path=path)
+        for k, v in op.last_kernel_ms.items():
+            acc[k] = acc.get(k, 0.0) + v / reps
+    st_ = op.run(x, path=path)["status"]
+    status_bad = int(((st_ & 1) != 0).sum().item())
+    general_frames = int(((st_ & 2) != 0).sum().item())
+    torch.cuda.synchronize()
+    ms_per_step = 1e3 * elapsed / steps
+    # a kernel whose blocks all exit at once still costs its dispatch (~6 us between two events): not a candidate
+    live = {k: v for k, v in acc.items() if v > 0}
+    dom = max(live, key=live.get)
+    algo_bytes = BYTES_PER_PIXEL * B * H * W
+    achieved = algo_bytes / (live[dom] * 1e-3) / 1e9
+    tr = None
+    t = (traffic or {}).get(workload or "", {})
+    if t.get("batch") == B and dom in t.get("kernels", {}):
+        k = t["kernels"][dom]
+        tr = k["fetch_bytes"] + k["write_bytes"]
+    roof = {
+        "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr, "algorithmic_bytes": algo_bytes,
+        "kernel_ms": {k: round(v, 4) for k, v in live.items()},
+        "pass_achieved_GBs": round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+        "pass_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "pass_traffic": t.get("pass_bytes") if t.get("batch") == B else None,
+    }
+    out = {"ms_per_step": round(ms_per_step, 4), "elapsed": elapsed, "frames_with_index_error": status_bad,
+           "frames_on_general_path": general_frames}
+    if rep:
+        srt = sorted(rep)
+        out["repeat"] = {"n": len(rep), "median_ms_per_step": round(srt[len(srt) // 2], 4),
+                         "min_ms_per_step": round(srt[0], 4), "max_ms_per_step": round(srt[-1], 4)}
+    return out, roof
 
 
 def main():
@@ -71,28 +159,50 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default: the workload's)")
     ap.add_argument("--workload", default="kitti_b32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--path", default="auto", choices=["auto", "general", "fused", "legacy"])
+    ap.add_argument("--no-extras", action="store_true", help="headline workload only (no workloads / end_to_end keys)")
+    ap.add_argument("--sharded", action="store_true", help="also time fill_sharded (host slab gather) at N=1")
+    ap.add_argument("--path", default="auto", choices=["auto", "general", "fused"])
     ap.add_argument("--metric", default="l1_cv", choices=["l1_cv", "l2"],
                     help="l1_cv = the reference's cv2 transform (headline); l2 = exact Euclidean")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher: start the ranks ourselves, BEFORE anything here touches a GPU (never exec from a GPU process)
+        import socket
+
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if world != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+
+    import numpy as np
+    import torch
+
     dist = None
     if world > 1 or os.environ.get("DTFILL_BENCH_FORCE_DIST"):  # the latter: exercise the RCCL path with one rank
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # one rank per GPU over RCCL.  DTFILL_BENCH_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs
         # than ranks (the ranks then share devices and the barrier / max run over gloo on the host).
         backend = os.environ.get("DTFILL_BENCH_BACKEND", "nccl")
         ndev = torch.cuda.device_count()
-        assert backend == "gloo" or local_rank < ndev, "rank %d has no GPU (%d visible)" % (local_rank, ndev)
+        if backend != "gloo" and local_rank >= ndev:
+            sys.exit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, ndev))
         torch.cuda.set_device(local_rank % ndev)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -106,84 +216,91 @@ def main():
     synth = importlib.import_module(PKG + ".synth")
     op = pkg.device.DtFill(device=dev, metric=args.metric)
 
-    cfg = synth.CONFIGS[args.workload]
-    xh = synth.make(args.workload, B=args.batch, seed=cfg["kwargs"]["seed"] + rank)
-    B, H, W = xh.shape
-    x = torch.from_numpy(xh).to(dev)
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        op.run(x, path=args.path)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        op.run(x, path=args.path)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    def reduce_max(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    # per-kernel durations (HIP events on the launch stream), mean over a few instrumented passes
-    reps = 10
-    acc = {}
-    for _ in range(reps):
-        op.run(x, timed=True, path=args.path)
-        for k, v in op.last_kernel_ms.items():
-            acc[k] = acc.get(k, 0.0) + v / reps
-    st_ = op.run(x, path=args.path)["status"]
-    status_bad = int(((st_ & 1) != 0).sum().item())
-    general_frames = int(((st_ & 2) != 0).sum().item())
-    torch.cuda.synchronize()
+    traffic = load_traffic()
+    cfg = synth.CONFIGS[args.workload]
+    B = args.batch or cfg["B"]
+    xh = synth.make(args.workload, B=B, seed=cfg["kwargs"]["seed"] + rank)
+    _, H, W = xh.shape
+    x = torch.from_numpy(xh).to(dev)
+    res, roof = measure(op, torch, x, args.steps, args.warmup, args.path, barrier, reduce_max, repeats=5,
+                        workload=args.workload, traffic=traffic)
+
+    sharded = None
+    if world > 1 or args.sharded:
+        # the numpy-out contract on N GPUs: every rank computes its shard of ONE batch of world * B frames and copies it
+        # from its GPU straight into its slice of the shared pinned host slab
+        xs = np.concatenate([synth.make(args.workload, B=B, seed=cfg["kwargs"]["seed"] + r) for r in range(world)])
+        tm = {}
+        pkg.fill_sharded(xs, metric=args.metric, dst=0, timings=tm)  # warm (allocations, pinning)
+        t0 = time.perf_counter()
+        pkg.fill_sharded(xs, metric=args.metric, dst=0, timings=tm)
+        total = reduce_max(time.perf_counter() - t0)
+        sharded = {"frames": int(xs.shape[0]), "total_ms": round(1e3 * total, 2),
+                   "h2d_compute_ms": round(reduce_max(tm["compute_ms"]), 2),
+                   "d2h_into_slab_ms": round(reduce_max(tm["gather_ms"]), 2),
+                   "frames_per_s_end_to_end": round(xs.shape[0] / total, 1)}
 
     if rank == 0:
         frames = world * B * args.steps
-        ms_per_step = 1e3 * elapsed / args.steps
-        acc = {k: v for k, v in acc.items() if v > 0}
-        dom = max(acc, key=acc.get)
-        traffic = None
-        try:  # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj.get("kernel") == dom and tj.get("workload") == args.workload and B == 32:
-                traffic = tj["fetch_bytes_corrected"] + tj["write_bytes"]
-        except (OSError, ValueError, KeyError):
-            pass
-        algo_bytes = BYTES_PER_PIXEL * B * H * W
-        achieved = algo_bytes / (acc[dom] * 1e-3) / 1e9
         line = {
             "metric": "DT+NN-fill frames/sec at 352x1216; achieved HBM GB/s vs peak",
-            "value": round(frames / elapsed, 1),
+            "value": round(frames / res["elapsed"], 1),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32",  # 32-pixel bit planes / byte codes; int32 index, f32 depth + distance only at the stores
+            "dtype": "u32",  # packed integer keys / 32-pixel bit planes; int32 index, f32 depth + distance only at the stores
             "data": "synthetic",
             "config": {
                 "workload": "%s: B=%d frames/GPU of %dx%d, %s" % (args.workload, B, H, W, json.dumps(cfg["kwargs"])),
                 "metric_mode": args.metric, "outputs": "depth+dt+index", "frames_per_gpu": B,
                 "parallelism": "frame-sharded x%d, no collective" % world,
             },
-            "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes": algo_bytes,
-                "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
-                "pass_achieved_GBs": round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                "pass_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            },
-            "frames_with_index_error": status_bad,
-            "frames_on_general_path": general_frames,
+            "roofline": roof,
+            "repeat": res.get("repeat"),
+            "frames_with_index_error": res["frames_with_index_error"],
+            "frames_on_general_path": res["frames_on_general_path"],
         }
+        if sharded:
+            line["sharded"] = sharded
+        if world == 1 and not args.no_extras and args.metric == "l1_cv" and args.workload == "kitti_b32":
+            wl = {}
+            for name in EXTRA_WORKLOADS:
+                c = synth.CONFIGS[name]
+                xw = torch.from_numpy(synth.make(name)).to(dev)
+                r, rf = measure(op, torch, xw, 20, 5, args.path, barrier, reduce_max, workload=name, traffic=traffic)
+                wl[name] = {"value": round(c["B"] * 20 / r["elapsed"], 1), "unit": "frames/s", "frames": c["B"],
+                            "shape": [c["H"], c["W"]], "ms_per_step": r["ms_per_step"], "roofline": rf,
+                            "frames_on_general_path": r["frames_on_general_path"]}
+                del xw
+            line["workloads"] = wl
+            # numpy in / numpy out through the reference-named function (H2D + pass + D2H, pinned staging)
+            e2e = {}
+            for nb in (1, B):
+                batch = xh[:nb, :, :, None]
+                pkg.DT_complete_batch(batch)
+                n = 20 if nb == 1 else 5
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    pkg.DT_complete_batch(batch)
+                e2e["B%d" % nb] = round(nb * n / (time.perf_counter() - t0), 1)
+            line["end_to_end"] = {"what": "DT_complete_batch numpy->numpy incl. PCIe, frames/s", **e2e}
         if world == 1 and not args.no_cpu_baseline and args.metric == "l1_cv":
             line["cpu_baseline"] = cpu_baseline(xh)
         print(json.dumps(line))

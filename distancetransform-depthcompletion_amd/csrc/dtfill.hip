@@ -7,43 +7,38 @@
 //
 // The reference's arithmetic is OpenCV's two-pass 5x5 chamfer: two raster sweeps that are sequential
 // in both image axes.  This file does NOT sweep.  It uses the following identity (derived in
-// DESIGN.md "Why no raster sweep", checked bit-for-bit against the sequential restatement in oracle/):
+// DESIGN.md section 2, checked bit-for-bit against the sequential restatement in oracle/):
 //
 //   d(q)      = exact L1 distance to the nearest source               (weights {1,2,3} == L1 norms of the taps)
 //   live(q)   = "the forward sweep already reached the final value at q"
 //             = some nearest source s of q lies in q's forward cone:  s above-or-left of q, or above-right
 //               with (s.col - q.col) <= 2 (q.row - s.row)
-//             = (dA(q) == d(q)) or (dB(q) == d(q)),  where with gu(i,k) = distance to the nearest source
-//               at-or-above row i in column k:
-//                 dA(i,j) = min_{k<=j} gu(i,k) + (j-k)                          (row prefix scan)
-//                 dB(i,j) = 3 + D(i-1,j+2),  D(i,j) = min(E(i,j), 3 + D(i-1,j+2)) (scan along knight lines)
-//                 E(i,j)  = min(gu(i,j), gu(i,j-1) - 1)
 //   parent(q) = live(q) ? first forward tap r (cv2 order) with live(r) and d(r)+w == d(q)
 //                       : first backward tap r (cv2 order) with d(r)+w == d(q)
 //   label(q)  = label(root of the parent chain) = 1 + raster rank of that source.
 //
-// Every quantity is a 1-D scan along image columns, rows or knight-move lines, or a 5x5 local rule,
-// so all pixels of all frames are processed in parallel; only the final chain walk is data dependent
-// (chain length <= d(q) hops).
-//
-// Locality: everything that decides label(q) lies inside the L1 ball of radius d(q) around q.  So a
-// tile plus a halo of FR pixels, held on chip, gives the exact result for every tile pixel with
-// d <= FR, and detects (d > FR) the ones it cannot decide.
+// Every hop lowers d by exactly the hop's L1 length, so a chain ends on a NEAREST source of its start pixel, and
+// everything that decides label(q) lies inside the L1 ball of radius d(q) around q.
 //
 // Kernels of one l1_cv pass:
-//   k_mask     source / value bit words (ballots) + per-row prefix popcounts       reads x once
-//   k_frame    per-frame row-count scan -> compaction ranks; frame facts; value list when the source
-//              and value masks of a frame differ (else depth_list[lbl-1] == x at the source pixel)
-//   k_fused<16>  one workgroup per (tile + halo 16) window, bit-sliced: the level-synchronous form of
-//              the identity above on bit planes held in registers (one lane per window row, taps as word
-//              shifts), byte codes un-sliced into LDS, lock-step chain walk, rank lookup, depth gather
-//              and the three output stores.  Flags the frame if any tile pixel has d > 16.
-//   k_fused<32>  the same with halo 32, only for frames the first stage flagged.
-//   general path (only frames k_fused<32> flagged too; blocks of other frames exit at once):
-//   k_colscan, k_skew, k_rowscan  full-frame column / knight-line / row scans through HBM (uint16)
-//   k_exit     5x5 parent rule + in-tile chain resolution by pointer doubling in LDS -> exit pointers
-//   k_final    follows the few tile-to-tile hops, rank -> label, gather, store.      Any distance.
-// l2 pass (exact Euclidean, canonical tie-break): k_mask, k_frame, k_colscan<true>, k_l2row.
+//   k_mask     source / value bit words + per-row prefix popcounts                    reads x once
+//   k_frame    per-frame row-count scan -> compaction ranks; frame facts; which kernel family takes the frame;
+//              value list when the source and value masks of a frame differ
+//   dense frames (every pixel within 16 of a source):
+//   k_fused<16>  one workgroup per (tile + halo 16) window, bit-sliced: the level-synchronous form of the
+//              identity on bit planes held in registers, byte codes un-sliced into LDS, lock-step chain walk,
+//              rank lookup, depth gather and the three output stores.  Hands the frame on if a tile pixel is
+//              farther than 16 from every source.
+//   every other frame (any distance, any density; dtfill_rows.hpp):
+//   k_labels   label of every source pixel, where k_fin can gather it
+//   k_colT     per 32-row band and column: the band's source bits and the distances to the nearest source
+//              above / below the band -- everything a row needs to know about its columns
+//   k_rows     packed-key min-plus row scans: d, the nearest source (smallest and largest column that reach d:
+//              a pixel with ONE nearest source needs no chain), live; distance map + bit planes
+//   k_fin      per tile: 5x5 parent rule bit-sliced for the remaining "tie" pixels, their chains (pointer
+//              doubling in LDS), label + depth of every pixel
+//   k_tiesx    the few tie pixels whose chain crosses tiles
+// l2 pass (exact Euclidean, canonical tie-break): k_mask, k_frame, k_colT, k_l2row.
 //
 // No MFMA anywhere: this path is compare/min/index work (DESIGN.md "Roofline").
 
@@ -63,7 +58,6 @@ namespace {
 #include "dtfill_common.hpp"
 #include "dtfill_prepass.hpp"
 #include "dtfill_fused.hpp"
-#include "dtfill_general.hpp"   // also k_colscan<true> used by the l2 pass
 #include "dtfill_rows.hpp"
 #include "dtfill_l2.hpp"
 #include "dtfill_outlier.hpp"
@@ -76,10 +70,8 @@ namespace {
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 struct Carve {
-    u16 *gu, *g, *dB;
-    u8 *planes;          // k_rowscan -> k_exit: four bit planes (d & 1, d >> 1 & 1, d >> 2 & 1, live), Wd * 8 bytes per row
+    u8 *planes;          // k_rows -> k_fin: bit planes d & 1, d >> 1 & 1, d >> 2 & 1, live, tie; k_fin -> k_tiesx: unresolved; Wd * 8 bytes per row
     size_t plane_bytes;  // bytes of one plane
-    u32 *exitp;
     u64 *srcbits, *valbits;
     u16 *wpre_s, *wpre_v;
     u32 *rowcnt_s, *rowcnt_v, *rowbase_s, *rowbase_v;
@@ -89,7 +81,7 @@ struct Carve {
     u32 *xlist, *xptr;   // k_fin -> k_tiesx: the pixels whose chain left their tile, and where each goes on
     u32 *spix;           // k_rows -> k_fin: per pixel, the frame offset of its nearest source in column kmin
     int32_t *labelmap;   // k_labels: at every source pixel, its label (1 + raster rank among the frame's sources)
-    int *finfo, *fflag, *fflag2, *status;
+    int *finfo, *fflag2, *status;
     float *vlist;
     size_t total;
 };
@@ -116,7 +108,6 @@ Carve carve(void *ws, int B, int H, int W) {
     c.rowbase_s = (u32 *)take(NR * 4);
     c.rowbase_v = (u32 *)take(NR * 4);
     c.finfo = (int *)take((size_t)B * FI_STRIDE * 4);
-    c.fflag = (int *)take((size_t)B * 4);
     c.fflag2 = (int *)take((size_t)B * 4);
     c.status = (int *)take((size_t)B * 4);
     // any-distance path (touched only for frames the fused kernel does not take)
@@ -127,12 +118,8 @@ Carve carve(void *ws, int B, int H, int W) {
     c.spix = (u32 *)take(N * 4);
     c.xlist = (u32 *)take(N * 4);
     c.xptr = (u32 *)take(N * 4);
-    c.gu = (u16 *)take(N * 2);
-    c.g = (u16 *)take(N * 2);
-    c.dB = (u16 *)take(N * 2);
     c.plane_bytes = align256(NW * 8);
     c.planes = (u8 *)take(PL_N * c.plane_bytes);
-    c.exitp = (u32 *)take(N * 4);
     c.vlist = (float *)take(N * 4);
     c.total = off;
     return c;
@@ -157,26 +144,6 @@ void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, flo
                                                                           c.rowcnt_v);
 }
 
-// the legacy any-distance kernels (column / knight-line / row scans through HBM, pointer doubling per tile)
-void launch_legacy_general(const float *x, int B, int H, int W, int Wd, const Carve &c, float *out_depth, float *out_dt,
-                           int32_t *out_index, int *status, hipStream_t st) {
-    const int N1 = H * W;
-    k_colscan<false><<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, c.fflag2, c.finfo, H, W, Wd, c.gu, c.g);
-    const int nU = W + 2 * (H - 1) + 1;
-    k_skew<<<dim3((nU + 63) / 64, B), 64 * G_NCH, 0, st>>>(c.gu, c.fflag2, c.finfo, H, W, c.dB);
-    const int nseg = (W + 511) / 512;
-    const size_t per_wave = (size_t)nseg * 512 * sizeof(int);  // <= 32 KiB at W = 8191
-    const int wpb = (int)max((size_t)1, min((size_t)4, (size_t)65536 / per_wave));
-    k_rowscan<<<dim3((H + wpb - 1) / wpb, B), 64 * wpb, wpb * per_wave, st>>>(c.g, c.gu, c.dB, c.fflag2, c.finfo, H, W, nseg,
-                                                                          Wd * 8, c.planes, c.plane_bytes, out_dt);
-    const int etx = (W + X_T - 1) / X_T, ety = (H + X_T - 1) / X_T;
-    k_exit<<<dim3(etx * ety, B), X_NT, 0, st>>>(c.planes, c.plane_bytes, Wd * 8, c.srcbits, Wd, c.finfo, c.fflag2, H, W, etx,
-                                                c.exitp, -1);
-    k_final<<<dim3((N1 + 256 * G_PPT - 1) / (256 * G_PPT), B), 256, 0, st>>>(x, c.exitp, c.srcbits, c.wpre_s, c.rowbase_s,
-                                                                             c.finfo, c.vlist, c.fflag2, H, W, Wd,
-                                                                             out_depth, out_index, status);
-}
-
 int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, float *out_depth,
            float *out_dt, int32_t *out_index, int32_t *frame_status, void *workspace, unsigned flags,
            hipStream_t st, hipEvent_t *ev) {
@@ -185,7 +152,6 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     int *status = frame_status ? frame_status : c.status;
     const bool general_only = flags & DTFILL_FLAG_GENERAL_ONLY;
     const bool fused_only = flags & DTFILL_FLAG_FUSED_ONLY;
-    const bool legacy = flags & DTFILL_FLAG_LEGACY_GENERAL;
     int k = 0;
     bool ok = true;
     auto mark = [&]() {
@@ -196,7 +162,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s,
-                               c.rowbase_v, c.finfo, c.vlist, c.fflag, c.fflag2, status, (general_only ? 1 : 0) | 2);
+                               c.rowbase_v, c.finfo, c.vlist, c.fflag2, status, general_only ? 1 : 0);
     mark();
     if (!general_only) {
         // dense frames: one window kernel (halo 16).  It hands a frame on (fflag2) when the frame is too sparse for
@@ -205,17 +171,14 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const int nty = (H + THM - 1) / THM, ntx = (W + TWM - 1) / TWM;
         const int TH = (H + nty - 1) / nty, TW = (W + ntx - 1) / ntx;  // even split
         k_fused<R><<<dim3(ntx * nty, B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd,
-                                                       TH, TW, ntx, out_depth, out_dt, out_index, nullptr, c.fflag2,
+                                                       TH, TW, ntx, out_depth, out_dt, out_index, c.fflag2,
                                                        status);
     }
     mark();
-    if (!fused_only && !legacy && (out_depth || out_index))  // label of every source pixel of the frames that go on
+    if (!fused_only && (out_depth || out_index))  // label of every source pixel of the frames that go on
         k_labels<<<dim3((H * Wd + 255) / 256, B), 256, 0, st>>>(c.srcbits, c.wpre_s, c.rowbase_s, c.fflag2, H, W, Wd, c.labelmap);
     mark();
-    if (!fused_only && legacy) {
-        launch_legacy_general(x, B, H, W, Wd, c, out_depth, out_dt, out_index, status, st);
-        for (int t = 0; t < 4; ++t) mark();
-    } else if (!fused_only) {
+    if (!fused_only) {
         // every other frame: argmin scans, any distance (dtfill_rows.hpp)
         const int nb = c.nb;
         const int cw = min(16, max(2, nb));
@@ -266,7 +229,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
 }
 
 constexpr int NK_L2 = 4;
-const char *const kNamesL2[NK_L2] = {"k_mask", "k_frame", "k_colscan", "k_l2row"};
+const char *const kNamesL2[NK_L2] = {"k_mask", "k_frame", "k_colT", "k_l2row"};
 
 int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, float *out_depth, float *out_dt,
            int32_t *out_index, int32_t *frame_status, void *workspace, hipStream_t st, hipEvent_t *ev) {
@@ -281,12 +244,16 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
-                               c.finfo, c.vlist, c.fflag, c.fflag2, status, 2);
+                               c.finfo, c.vlist, c.fflag2, status, 0);
     mark();
-    k_colscan<true><<<dim3(Wd, B), 64 * G_NCH, 0, st>>>(c.srcbits, nullptr, nullptr, H, W, Wd, c.gu, c.g);
+    {
+        const int cw = min(16, max(2, c.nb));
+        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, (size_t)c.nb * 64 * 2 * sizeof(u16), st>>>(c.srcbits, nullptr, H, W, Wd, c.nb,
+                                                                                           c.ctp, c.ct);
+    }
     mark();
-    k_l2row<<<dim3(H, B), 256, (size_t)W * sizeof(u16), st>>>(x, c.g, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W,
-                                                         Wd, out_depth, out_dt, out_index, status);
+    k_l2row<<<dim3(H, B), 256, (size_t)W * sizeof(u16), st>>>(x, c.ct, c.ctp, c.nb, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist,
+                                                         H, W, Wd, out_depth, out_dt, out_index, status);
     mark();
     return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }

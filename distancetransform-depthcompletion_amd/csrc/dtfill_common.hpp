@@ -4,20 +4,12 @@
 
 constexpr int BIG = 1 << 20;       // in-register "infinite" distance
 constexpr int INF16 = 0xFFFF;      // stored "infinite" distance in the uint16 scan arrays
-constexpr int DL_DMASK = 0x3FFF;   // dl: low 14 bits = d
-constexpr int DL_NONE = 0x3FFF;    // dl: no source in the frame
-constexpr int DL_LIVE = 0x8000;    // dl: live flag
-constexpr int PAR_SRC = 0xFF;      // parent code: pixel is a source
-constexpr int PAR_NONE = 0xFE;     // parent code: unreachable / undecided
 constexpr int MAX_HW_SUM = 8192;   // cv2's Q16 INIT_DIST0 = INT_MAX>>2 caps distances at 8191
 
 // frame facts written by k_frame: int32[FI_STRIDE] per frame
-constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_DLB = 3;  // DLB: lower bound of max d (band mode: below the band)
-// Band mode (an empty band on top of an otherwise dense frame): the general kernels own rows [0, RW) and
-// compute on rows [0, HG) only, the fused stages own rows [RW, H).  Otherwise RW = HG = H.
-constexpr int FI_RW = 4, FI_HG = 5, FI_STRIDE = 8;
-constexpr int FI_NUNRES = 6;  // tie pixels k_ties handed to k_tiesx (zeroed by k_frame)
-constexpr int BAND_MARGIN = 65;  // HG = RW + 2 * 32 + 1: no source at or beyond that row can be nearest to (or tie for) a pixel above RW
+constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_DLB = 3;  // DLB: lower bound of the largest distance (empty rows)
+constexpr int FI_NUNRES = 4;  // tie pixels k_fin handed to k_tiesx (zeroed by k_frame)
+constexpr int FI_STRIDE = 8;
 
 // cv2 tap order (OpenCV 3.4 distanceTransformEx_5x5), forward taps 0..7; backward tap t is the
 // NEGATED forward tap t with the same weight.  Parent code = t | (backward ? 8 : 0).
@@ -37,8 +29,3 @@ __device__ __forceinline__ void tap_decode(int code, int &di, int &dj) {
     }
 }
 
-__device__ __forceinline__ int ld16(const u16 *p) {
-    int v = *p;
-    return v == INF16 ? BIG : v;
-}
-__device__ __forceinline__ u16 st16(int v) { return (u16)(v >= INF16 ? INF16 : v); }

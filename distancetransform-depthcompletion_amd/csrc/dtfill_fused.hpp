@@ -21,8 +21,6 @@
 // undecided), which reuses the ring's memory, and the tile pixels walk to their sources in lock-step:
 // the byte is the byte offset of the step's s_par displacement in a 64-entry int16 table (s_tab), so a
 // hop is two LDS reads and one add; d is |drow| + |dcol| to the root.
-// Band mode (finfo FI_RW < H): rows above FI_RW belong to the general kernels -- tiles entirely above are skipped,
-// undecided pixels above are not reported.
 // LDS: 28.9 KB ring/s_par + 8 KB rank records.
 // ------------------------------------------------------------------------------------------------
 constexpr int F_WHM = 128;  // window rows
@@ -122,7 +120,7 @@ __device__ __forceinline__ void ring_store3(u32 *__restrict__ ring, int slot, in
 template <int FR, int NT>
 __device__ __forceinline__ bool fused_walk_epilogue(
     const u8 *__restrict__ s_par, const short *__restrict__ s_tab, const uint2 *__restrict__ s_rw, int b, int H,
-    int W, int th, int tw, int r0, int c0, int wr0, int wc0, int sh, int rw_lo, const float *__restrict__ x,
+    int W, int th, int tw, int r0, int c0, int wr0, int wc0, int sh, const float *__restrict__ x,
     const float *__restrict__ vlist,
     const int *__restrict__ finfo, float *__restrict__ out_depth, float *__restrict__ out_dt,
     int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
@@ -178,8 +176,8 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             pos[e] = __mul24(FR + tr, F_P) + FR + tc;
             code[e] = s_par[pos[e]];
             ok |= (p < npx && code[e] != F_NONE) ? (1u << e) : 0u;
-            // undecidable here: the frame goes on to the next stage (band mode: rows above rw_lo are not ours)
-            overflow |= p < npx && code[e] == F_NONE && r0 + tr >= rw_lo;
+            // undecidable here: the any-distance kernels take the frame
+            overflow |= p < npx && code[e] == F_NONE;
         }
         // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
         // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
@@ -248,16 +246,15 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     return overflow;
 }
 
-// FR = halo = largest distance the window can decide.  gate (nullable): only frames with gate[b] != 0
+// FR = halo = largest distance the window can decide.
 // are processed (the second, FR = 32 stage only redoes the frames the FR = 16 stage flagged).
 template <int FR>
 __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
     int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
-    float *__restrict__ out_dt, int32_t *__restrict__ out_index, const int *__restrict__ gate,
+    float *__restrict__ out_dt, int32_t *__restrict__ out_index,
     int *__restrict__ fflag, int *__restrict__ frame_status) {
-    if (gate && !gate[blockIdx.y]) return;
     if (fflag[blockIdx.y]) return;  // the any-distance kernels take this frame (k_frame's choice)
     // Speed heuristic only (never correctness): with source density p the chance that a pixel has no source
     // within L1 distance FR is about (1-p)^(2 FR^2 + 2 FR + 1); if the frame is expected to hold such a pixel
@@ -265,7 +262,6 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     // all the work -- hand it on right away.  Likewise when k_frame found a run of source-free rows that forces
     // some distance above FR (real LiDAR frames: the empty sky rows).  (The two finfo loads are issued together
     // with the window loads below; the branch comes after those are in flight.)
-    const int h_rw = finfo[blockIdx.y * FI_STRIDE + FI_RW];  // band mode (h_rw < H): rows above belong to the general kernels
     __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
     // per window row, the eight image-aligned 32-pixel half words it touches: {source bits, sources before them
     // in frame raster order} -- one 8-byte LDS read and a 32-bit popcount per rank lookup
@@ -278,8 +274,6 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * TH, c0 = tx * TW;
     const int th = min(TH, H - r0), tw = min(TW, W - c0);
-    const int rw_lo = h_rw < H ? h_rw : 0;  // first image row this stage is responsible for
-    if (r0 + th <= rw_lo) return;           // tile entirely above it (block-uniform)
     const int wr0 = r0 - FR, wc0 = c0 - FR;  // image coords of window cell (0,0)
     const int WH = th + 2 * FR, WW = tw + 2 * FR;
     const int ca = max(0, -wc0), cb = min(WW, W - wc0);  // in-image window columns [ca, cb)
@@ -337,7 +331,7 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
             // tile columns of window word wb + i: [FR, FR + tw) -- rows [FR, FR + th)
             const int tlo = max(FR - 32 * (wb + i), 0), tup = min(FR + tw - 32 * (wb + i), 32);
             u32 tm = 0;
-            if (r >= FR && r < FR + th && r0 + r - FR >= rw_lo && tup > tlo) tm = (tup >= 32 ? 0xFFFFFFFFu : ((1u << tup) - 1u)) & ~((1u << tlo) - 1u);
+            if (r >= FR && r < FR + th && tup > tlo) tm = (tup >= 32 ? 0xFFFFFFFFu : ((1u << tup) - 1u)) & ~((1u << tlo) - 1u);
             TM[i] = tm;
         }
     }
@@ -500,7 +494,7 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     }
     __syncthreads();
 
-    const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_tab, s_rw, b, H, W, th, tw, r0, c0, wr0, wc0, sh, rw_lo, x, vlist,
+    const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_tab, s_rw, b, H, W, th, tw, r0, c0, wr0, wc0, sh, x, vlist,
                                                         finfo, out_depth, out_dt, out_index, frame_status);
     if (overflow) {
         fflag[b] = 1;  // same-value race: every writer stores 1, the any-distance kernels read it after this kernel

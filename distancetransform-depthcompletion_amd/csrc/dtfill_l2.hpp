@@ -4,12 +4,12 @@
 
 // ------------------------------------------------------------------------------------------------
 // l2 metric: k_l2row.  One lane per pixel.  With g(i,k) the vertical distance to the nearest source of
-// column k, the exact squared Euclidean distance is min_k g(i,k)^2 + (j-k)^2; the columns are visited
+// column k (from k_colT's band words), the exact squared Euclidean distance is min_k g(i,k)^2 + (j-k)^2; the columns are visited
 // outward from j (r = |j-k| = 0,1,2,...) and the search stops once r^2 exceeds the best value, so the
 // work per pixel is ~2 sqrt(d^2) candidates.  Ties go to the smallest raster index of the SOURCE
 // (smaller row, then smaller column) -- the order brute force gives.  Then rank -> label, gather, store.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_l2row(const float *__restrict__ x, const u16 *__restrict__ g,
+__global__ __launch_bounds__(256) void k_l2row(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
                                                const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
                                                const u32 *__restrict__ rowbase_s, const int *__restrict__ finfo,
                                                const float *__restrict__ vlist, int H, int W, int Wd,
@@ -20,8 +20,19 @@ __global__ __launch_bounds__(256) void k_l2row(const float *__restrict__ x, cons
     const int b = blockIdx.y, i = blockIdx.x;
     const size_t fo = (size_t)b * H * W;
     {
-        const u16 *grow_g = g + fo + (size_t)i * W;
-        for (int k = threadIdx.x; k < W; k += 256) s_grow[k] = grow_g[k];
+        // vertical distance to the nearest source of every column, from k_colT's band words (as in k_rows); bit 15:
+        // that source is BELOW this row (strictly nearer than the one above: on a vertical tie the upper source has the
+        // smaller raster index)
+        const int band = i >> 5, r = i & 31;
+        const uint2 *crow = ct + ((size_t)b * nb + band) * CTP;
+        const u32 upmask = (2u << r) - 1u;
+        for (int k = threadIdx.x; k < W; k += 256) {
+            const uint2 c = crow[k];
+            const u32 gu = min(ffbh_u32(c.x & upmask) + (u32)(r - 31), (c.y & 0xFFFFu) + (u32)r);
+            const u32 gd = min(ffbl_b32(c.x >> r), (c.y >> 16) + (u32)(31 - r));
+            const u32 m = min(gu, gd);
+            s_grow[k] = m >= (u32)MAX_HW_SUM ? (u16)INF16 : (u16)(m | (gd < gu ? 0x8000u : 0u));  // >= 8192: no source in the column
+        }
     }
     __syncthreads();
     const u16 *grow = s_grow;

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
                                                const u32 *__restrict__ rowcnt_v, int H, int W, int Wd,
                                                u32 *__restrict__ rowbase_s, u32 *__restrict__ rowbase_v,
                                                int *__restrict__ finfo, float *__restrict__ vlist,
-                                               int *__restrict__ fflag, int *__restrict__ fflag2,
+                                               int *__restrict__ fflag2,
                                                int *__restrict__ frame_status, int mode) {
     const bool force_general = mode & 1;  // every frame takes the any-distance kernels (tests)
     __shared__ u32 s_ws[4], s_wv[4];
@@ -269,14 +269,11 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     __syncthreads();
     const int misaligned = s_mis;
     if (tid == 0) {
-        finfo[b * FI_STRIDE + FI_RW] = H;
-        finfo[b * FI_STRIDE + FI_HG] = H;
         finfo[b * FI_STRIDE + FI_NSRC] = (int)run_s;
         finfo[b * FI_STRIDE + FI_NVAL] = (int)run_v;
         finfo[b * FI_STRIDE + FI_MISALIGNED] = misaligned;
         finfo[b * FI_STRIDE + FI_DLB] = s_dlb;
         finfo[b * FI_STRIDE + FI_NUNRES] = 0;
-        fflag[b] = 0;
         // Which kernel family takes the frame -- a speed heuristic, never a correctness condition (the window kernel
         // itself hands on every frame in which it meets a pixel it cannot decide).  With source density p the chance
         // that a pixel has no source within L1 distance 16 is about (1-p)^545; if the frame is expected to hold such

@@ -55,15 +55,14 @@ extern "C" {
                                        a label addresses past the value list, or label 0 (no source in
                                        the frame) with an empty value list.  out_depth of that frame is
                                        then unspecified; out_dt / out_index are still exact. */
-#define DTFILL_FRAME_GENERAL_PATH 2 /* informational (l1_cv): the frame held a pixel farther than 32 pixels
-                                       from every source and was computed by the full-frame (any-distance)
-                                       kernels instead of the LDS tile kernels; results are identical. */
+#define DTFILL_FRAME_GENERAL_PATH 2 /* informational (l1_cv): the frame was computed by the any-distance kernels
+                                       (sparse frame, or a pixel farther than 16 pixels from every source)
+                                       instead of the LDS window kernel; results are identical. */
 
 /* flags of dtfill_batch_flags(): path selection, for tests and benchmarks */
-#define DTFILL_FLAG_GENERAL_ONLY 1u /* skip the fused tile kernels, every frame takes the general path */
-#define DTFILL_FLAG_FUSED_ONLY   2u /* skip the general kernels: frames that need them are left
+#define DTFILL_FLAG_GENERAL_ONLY 1u /* skip the window kernel, every frame takes the any-distance kernels */
+#define DTFILL_FLAG_FUSED_ONLY   2u /* skip the any-distance kernels: frames that need them are left
                                        undefined and carry DTFILL_FRAME_GENERAL_PATH in their status */
-#define DTFILL_FLAG_LEGACY_GENERAL 4u /* any-distance frames through the round-1 kernels (A/B tests only) */
 
 int dtfill_abi_version(void);
 const char *dtfill_strerror(int code);

@@ -9,7 +9,7 @@ tail -12 gpurun_out/pytest_gpu.log
 for wl in "kitti_b32 32" "kitti_b32_scanline 32" "nyu_b64 64" "synth2048_b16 16"; do
   set -- $wl
   for path in ${PATHS:-auto}; do
-    timeout -k 10 120 python bench.py --workload $1 --batch $2 --steps 20 --warmup 5 --no-cpu-baseline --path $path \
+    timeout -k 10 120 python bench.py --workload $1 --batch $2 --steps 20 --warmup 5 --no-cpu-baseline --no-extras --path $path \
       > gpurun_out/bench_$1_$path.json 2> gpurun_out/bench_$1_$path.err || { echo "bench $1 $path failed"; tail -5 gpurun_out/bench_$1_$path.err; exit 1; }
     python - <<PY
 import json

@@ -4,7 +4,7 @@ wl=${1:-kitti_b32_scanline}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$wl
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --workload $wl > $out/trace.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --workload $wl > $out/trace.log 2>&1 || exit 1
 cd $GRAFT_REPO_ROOT
 python3 - "$out" "$wl" <<'PY' > $out/summary.txt
 import csv, glob, re, sys

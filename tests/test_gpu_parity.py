@@ -2,6 +2,7 @@
 golden vectors.  Bar: bit-exact distance map, label map and gathered depth (integer / index work;
 the float outputs are exact copies or integer-valued, so the float tolerance is 0)."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -544,3 +545,106 @@ def test_stray_points_in_the_sky(gpu_op, oracle):
     x = np.stack(frames)
     assert_equal_to_oracle(oracle, gpu_op, x)
     assert run(gpu_op, x, path="auto")["general"].all()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json's configurations at the sizes and variants SURVEY 8d states
+# ------------------------------------------------------------------------------------------------
+def test_config1_one_kitti_frame_through_the_reference_functions(pkg, oracle):
+    """Config 1 (plumbing shape): ONE 352x1216 frame through nearest_point / DT_complete_batch /
+    Distance_Transform, numpy in / numpy out, as demo.py:289-290 and eval_NYU.py:195 call them."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    x = synth.make("kitti_b1")[0]
+    dt, lbl = pkg.nearest_point(x)
+    dt0, lbl0 = oracle.nearest_point(x)
+    assert dt.shape == (352, 1216) and np.array_equal(dt, dt0) and np.array_equal(lbl, lbl0)
+    batch = x[None, :, :, None]
+    out = pkg.DT_complete_batch(batch)
+    assert out.shape == (1, 352, 1216, 1) and out.dtype == np.float32
+    assert np.array_equal(out, oracle.DT_complete_batch(batch))
+    one = pkg.Distance_Transform(batch, 0.1)  # the notebooks' thresholds (0.1 / 0.1)
+    assert one.shape == (352, 1216) and np.array_equal(one, oracle.Distance_Transform(batch, 0.1))
+    # a LiDAR-like frame (empty sky, ring rows) takes the other kernel family through the same functions
+    xs = synth.make("kitti_b32_scanline", B=1)[0]
+    assert np.array_equal(pkg.Distance_Transform(xs[None, :, :, None], 0.1), oracle.Distance_Transform(xs, 0.1))
+
+
+@pytest.mark.parametrize("n", [20, 50, 200, 500])
+def test_config4_nyu_b64_every_sampling_rate(gpu_op, oracle, pkg, n):
+    """Config 4: B=64 frames 480x640 with the reference's sampling pattern (data_read.py:360-364) at the rates the
+    drivers use (eval_NYU.py:40: 200; train.py:182-189: 20 / 50 / 500), every frame against the oracle."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    x = synth.nyu_pattern(64, n=n, seed=100 + n)
+    depth, dt, lbl, status = oracle.fill_batch(x)
+    got = run(gpu_op, x)
+    assert np.array_equal(got["dt"], dt) and np.array_equal(got["index"], lbl)
+    assert np.array_equal(got["depth"], depth) and not got["status"].any() and not status.any()
+    assert got["general"].all()  # 20 .. 500 points in 307200 pixels: never the window kernel
+
+
+def test_config4_nyu_misaligned_thresholds_full_size(gpu_op, oracle, pkg):
+    """eval_NYU.py's own thresholds on NYU-range depths: sources are x >= 0.999 (eval_NYU.py:115) but the value list
+    is x > 0.1 (:124), and depths start near 0.7 m -- every value in (0.1, 0.999) shifts the labels that follow it
+    (SURVEY 0 fact 3).  480x640, B=8, against the oracle."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    x = synth.nyu_pattern(8, n=200, seed=9, lo=0.7, hi=10.0)
+    assert ((x > 0.1) & (x < 0.999)).any()
+    assert_equal_to_oracle(oracle, gpu_op, x, st=0.001, vt=0.1)
+    one = x[3]
+    assert np.array_equal(pkg.Distance_Transform(one[None, :, :, None]), oracle.Distance_Transform(one))  # defaults: 0.001 / 0.1
+
+
+def test_config5_synth2048_b16_properties(gpu_op, oracle, pkg):
+    """Config 5's per-GPU share at full size (B=16 frames of 2048x2048, 1 % valid): size-independent properties on
+    every frame, the full oracle comparison on two of them."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    x = synth.make("synth2048_b16")
+    got = run(gpu_op, x)
+    B, H, W = x.shape
+    ii, jj = np.indices((H, W), dtype=np.int32)
+    for b in range(B):
+        src = x[b] >= 0.9
+        pos = np.argwhere(src).astype(np.int32)
+        lbl = got["index"][b]
+        assert lbl.min() >= 1 and lbl.max() <= len(pos)
+        l1 = np.abs(ii - pos[lbl - 1, 0]) + np.abs(jj - pos[lbl - 1, 1])  # every label is a true L1-nearest source
+        assert np.array_equal(l1.astype(np.float32), got["dt"][b])
+        assert np.array_equal(lbl[src], np.arange(1, len(pos) + 1))
+        assert np.array_equal(got["depth"][b], x[b][pos[lbl - 1, 0], pos[lbl - 1, 1]])
+    for b in (0, 15):
+        depth, dt, lbl, status = oracle.fill_batch(x[b : b + 1])
+        assert np.array_equal(got["dt"][b], dt[0]) and np.array_equal(got["index"][b], lbl[0])
+        assert np.array_equal(got["depth"][b], depth[0])
+
+
+def test_fill_sharded_on_the_gpu(pkg, oracle):
+    """The multi-GPU entry point with the real operator: one rank here (the group of one), so the shard is the whole
+    batch and the device-to-host copies land in the shared pinned slab; two ranks when the box has two GPUs."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    x = np.where(rng.random((5, 96, 320)) < 0.05, rng.uniform(1, 80, (5, 96, 320)), 0).astype(np.float32)
+    x[2, :60] = 0  # one frame for the any-distance kernels
+    depth, dt, lbl, _ = oracle.fill_batch(x)
+    tm = {}
+    out = pkg.fill_sharded(x, timings=tm)
+    assert np.array_equal(out["depth"], depth) and np.array_equal(out["dt"], dt) and np.array_equal(out["index"], lbl)
+    assert tm["compute_ms"] > 0 and tm["gather_ms"] >= 0
+    xb = x.copy()
+    xb[4] = 0  # numpy's IndexError in depth_list[label_list-1] (tools.py:26): raised for the batch
+    with pytest.raises(IndexError):
+        pkg.fill_sharded(xb)
+    assert np.array_equal(pkg.fill_sharded(xb, want=("dt",))["dt"], oracle.fill_batch(xb)[1])
+    if torch.cuda.device_count() >= 2:
+        import socket
+        import subprocess
+        import sys
+
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sharded_worker.py")
+        rc = subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), worker])
+        assert rc == 0

@@ -51,7 +51,7 @@ def _worker(rank, world, port, n_frames, q):
     if rank == 0:
         ok = ok and np.array_equal(root_only["index"], idx)
     else:
-        ok = ok and root_only["index"] is None
+        ok = ok and root_only is None
     # a frame that makes numpy raise IndexError (no source, empty value list) in the LAST rank's shard: every rank must
     # raise, none may hang in a collective (the reference raises once for the whole batch, tools.py:26)
     xb = x.copy()
