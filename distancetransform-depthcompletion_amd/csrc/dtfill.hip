@@ -30,9 +30,9 @@
 //              rank lookup, depth gather and the three output stores.  Hands the frame on if a tile pixel is
 //              farther than 16 from every source.
 //   every other frame (any distance, any density; dtfill_rows.hpp):
-//   k_labels   label of every source pixel, where k_fin can gather it
 //   k_colT     per 32-row band and column: the band's source bits and the distances to the nearest source
-//              above / below the band -- everything a row needs to know about its columns
+//              above / below the band -- everything a row needs to know about its columns; and the label of
+//              every source pixel, where k_fin can gather it
 //   k_rows     packed-key min-plus row scans: d, the nearest source (smallest and largest column that reach d:
 //              a pixel with ONE nearest source needs no chain), live; distance map + bit planes
 //   k_fin      per tile: 5x5 parent rule bit-sliced for the remaining "tie" pixels, their chains (pointer
@@ -130,8 +130,8 @@ bool shape_ok(int B, int H, int W) {
            (long long)B * H * W < (1ll << 31);  // B is a grid dimension; pixel indices are 32-bit
 }
 
-constexpr int NK_L1 = 8;
-const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_labels", "k_colT", "k_rows", "k_fin", "k_tiesx"};
+constexpr int NK_L1 = 7;
+const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_colT", "k_rows", "k_fin", "k_tiesx"};
 
 // k_mask4 when the rows can be read 16 bytes at a time, k_mask otherwise (same outputs)
 void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, float val_thr, const Carve &c, hipStream_t st) {
@@ -175,15 +175,12 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
                                                        status);
     }
     mark();
-    if (!fused_only && (out_depth || out_index))  // label of every source pixel of the frames that go on
-        k_labels<<<dim3((H * Wd + 255) / 256, B), 256, 0, st>>>(c.srcbits, c.wpre_s, c.rowbase_s, c.fflag2, H, W, Wd, c.labelmap);
-    mark();
     if (!fused_only) {
         // every other frame: argmin scans, any distance (dtfill_rows.hpp)
         const int nb = c.nb;
-        const int cw = min(16, max(2, nb));
-        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, (size_t)nb * 64 * 2 * sizeof(u16), st>>>(c.srcbits, c.fflag2, H, W, Wd, nb,
-                                                                                         c.ctp, c.ct);
+        const int cw = min(16, max(2, (nb + 1) / 2));
+        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, (size_t)nb * 64 * 2 * sizeof(u16), st>>>(
+            c.srcbits, c.fflag2, H, W, Wd, nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s, (out_depth || out_index) ? c.labelmap : nullptr);
         mark();
         const int Wp = Wd * 8;
         // columns per lane: 8 or 10, whichever leaves fewer idle lanes in the row's last wave
@@ -247,9 +244,9 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
                                c.finfo, c.vlist, c.fflag2, status, 0);
     mark();
     {
-        const int cw = min(16, max(2, c.nb));
+        const int cw = min(16, max(2, (c.nb + 1) / 2));
         k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, (size_t)c.nb * 64 * 2 * sizeof(u16), st>>>(c.srcbits, nullptr, H, W, Wd, c.nb,
-                                                                                           c.ctp, c.ct);
+                                                                                           c.ctp, c.ct, nullptr, nullptr, nullptr);
     }
     mark();
     k_l2row<<<dim3(H, B), 256, (size_t)W * sizeof(u16), st>>>(x, c.ct, c.ctp, c.nb, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist,

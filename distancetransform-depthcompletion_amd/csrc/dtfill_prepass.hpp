@@ -303,30 +303,6 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_labels: one thread per 64-pixel word of the source bits: labelmap[source pixel] = its label = 1 + its raster rank
-// among the frame's sources (cv2's label init: k = 1; every zero pixel of the mask gets k++).  Only source pixels
-// are written (and only those are ever read): 4 bytes per source, so that "label of the source at (i, j)" is one
-// gather for every later kernel instead of three loads and a 64-bit popcount.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_labels(const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
-                                                const u32 *__restrict__ rowbase_s, const int *__restrict__ fflag,
-                                                int H, int W, int Wd, int32_t *__restrict__ labelmap) {
-    const int b = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
-    if ((fflag && !fflag[b]) || w >= H * Wd) return;
-    const size_t wi = (size_t)b * H * Wd + w;
-    u64 bits = srcbits[wi];
-    if (!bits) return;
-    const int i = w / Wd, j0 = (w - i * Wd) * 64;
-    int32_t lab = (int32_t)(rowbase_s[(size_t)b * H + i] + wpre_s[wi]);
-    int32_t *row = labelmap + ((size_t)b * H + i) * W + j0;
-    while (bits) {
-        const int k = __ffsll((long long)bits) - 1;
-        bits &= bits - 1;
-        row[k] = ++lab;
-    }
-}
-
 // label of the source at (i, j): 1 + number of sources before it in raster order
 __device__ __forceinline__ int source_rank(u32 base, u64 word, int j) {
     return (int)base + __popcll(word & ((1ull << (j & 63)) - 1ull)) + 1;

@@ -44,32 +44,61 @@ constexpr int PL_D0 = 0, PL_D1 = 1, PL_D2 = 2, PL_LIVE = 3, PL_TIE = 4, PL_UNRES
 __host__ __device__ inline int ct_pitch(int W) { return ((W + 63) / 64) * 64 + 640; }
 
 __global__ __launch_bounds__(1024) void k_colT(const u64 *__restrict__ srcbits, const int *__restrict__ fflag, int H,
-                                               int W, int Wd, int nb, int CTP, uint2 *__restrict__ ct) {
+                                               int W, int Wd, int nb, int CTP, uint2 *__restrict__ ct,
+                                               const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
+                                               int32_t *__restrict__ labelmap) {
     extern __shared__ u16 s_lf[];  // [nb][64] last source row of the band, [nb][64] first (0xFFFF: none)
+    __shared__ u64 s_rowword[16][64];
     const int b = blockIdx.y, wd = blockIdx.x, lane = threadIdx.x & 63;
     const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
     if (fflag && !fflag[b]) return;
     const int j = wd * 64 + lane;
     const bool real = wd < Wd;  // block-uniform: word columns beyond the image only write the "no source" padding
-    const u64 *sbf = srcbits + (size_t)b * H * Wd + min(wd, Wd - 1);
     u16 *s_last = s_lf, *s_first = s_lf + nb * 64;
-    for (int band = ch; band < nb; band += nwv) {
-        const int i0 = band * 32, i1 = min(i0 + 32, H);
-        u32 bits = 0;
-        if (real) {
+    // A wave takes 64 consecutive rows = two bands at a time; lane = row: ONE load per row brings its word (and what its
+    // labels need), 64 ballots transpose the 64 x 64 bits, lane = column afterwards.
+    for (int band = 2 * ch; band < nb; band += 2 * nwv) {
+        const int row = band * 32 + lane;
+        u64 w = 0;
+        u32 base = 0;
+        if (real && row < H) {
+            const size_t wi = ((size_t)b * H + row) * Wd + wd;
+            w = srcbits[wi];
+            if (labelmap) base = rowbase_s[(size_t)b * H + row] + wpre_s[wi];
+        }
+        // transpose the 64 x 64 bits through LDS: every lane reads the 64 row words (one broadcast read each) and keeps
+        // its column's bit of each -- lane = column afterwards
+        s_rowword[ch][lane] = w;
+        u32 t_lo = 0, t_hi = 0;  // the column's source bits of band / band + 1
 #pragma unroll
-            for (int kb = 0; kb < 32; kb += 16) {  // wave-uniform addresses: scalar loads, 16 in flight
-                u64 w[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) w[k] = sbf[(size_t)min(i0 + kb + k, i1 - 1) * Wd];
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (i0 + kb + k < i1) bits |= (u32)((w[k] >> lane) & 1ull) << (kb + k);
+        for (int rr = 0; rr < 32; ++rr) {
+            t_lo |= (u32)((s_rowword[ch][rr] >> lane) & 1ull) << rr;
+            t_hi |= (u32)((s_rowword[ch][rr + 32] >> lane) & 1ull) << rr;
+        }
+        if (labelmap && w) {
+            // label of every source pixel of this row: 1 + raster rank among the frame's sources (cv2's label init:
+            // k = 1; every zero pixel of the mask gets k++) = sources in the rows before + in the words before + before
+            // it in the word.  Only source pixels are written (and only those are ever read).
+            int32_t *lrow = labelmap + ((size_t)b * H + row) * W + wd * 64;
+            u64 m = w;
+            u32 lab = base;
+            while (m) {
+                const int k = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                lrow[k] = (int32_t)++lab;
             }
         }
-        if (j < CTP) ct[((size_t)b * nb + band) * CTP + j].x = bits;
-        s_last[band * 64 + lane] = bits ? (u16)(i0 + 31 - __clz((int)bits)) : (u16)0xFFFF;
-        s_first[band * 64 + lane] = bits ? (u16)(i0 + __ffs((int)bits) - 1) : (u16)0xFFFF;
+        if (j < CTP) {
+            ct[((size_t)b * nb + band) * CTP + j].x = t_lo;
+            if (band + 1 < nb) ct[((size_t)b * nb + band + 1) * CTP + j].x = t_hi;
+        }
+        const int i0 = band * 32;
+        s_last[band * 64 + lane] = t_lo ? (u16)(i0 + 31 - __clz((int)t_lo)) : (u16)0xFFFF;
+        s_first[band * 64 + lane] = t_lo ? (u16)(i0 + __ffs((int)t_lo) - 1) : (u16)0xFFFF;
+        if (band + 1 < nb) {
+            s_last[(band + 1) * 64 + lane] = t_hi ? (u16)(i0 + 63 - __clz((int)t_hi)) : (u16)0xFFFF;
+            s_first[(band + 1) * 64 + lane] = t_hi ? (u16)(i0 + 32 + __ffs((int)t_hi) - 1) : (u16)0xFFFF;
+        }
     }
     __syncthreads();
     if (ch == 0) {  // distance from the band's FIRST row to the nearest source above the band (low half)
