@@ -284,8 +284,8 @@ def main():
             for name in EXTRA_WORKLOADS:
                 c = synth.CONFIGS[name]
                 xw = torch.from_numpy(synth.make(name)).to(dev)
-                r, rf = measure(op, torch, xw, 20, 5, args.path, barrier, reduce_max, workload=name, traffic=traffic)
-                wl[name] = {"value": round(c["B"] * 20 / r["elapsed"], 1), "unit": "frames/s", "frames": c["B"],
+                r, rf = measure(op, torch, xw, 30, 10, args.path, barrier, reduce_max, workload=name, traffic=traffic)
+                wl[name] = {"value": round(c["B"] * 30 / r["elapsed"], 1), "unit": "frames/s", "frames": c["B"],
                             "shape": [c["H"], c["W"]], "ms_per_step": r["ms_per_step"], "roofline": rf,
                             "frames_on_general_path": r["frames_on_general_path"]}
                 del xw

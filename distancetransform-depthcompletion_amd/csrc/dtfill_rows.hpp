@@ -406,11 +406,7 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
 constexpr int Q_TH = 32, Q_TW = 256;
 constexpr int Q_NT = 256;
 constexpr int Q_WW = Q_TW / 32;  // tile words per row
-constexpr u32 P_IDX = 0x1FFFu, P_EXIT = 0x4000u, P_TERM = 0x8000u;  // s_ptr: tile index (row * 256 + column), flags
-constexpr u32 B_MULTI = 0x80u;                                       // s_byte: the pixel's parent is a tie pixel too
-constexpr u32 P_UNRES = 0xFFFFu;                                     // s_ptr, final form: chain goes on in another tile
-constexpr int Q_LW = Q_TW + 64;                                      // s_ptr, final form: (row + 2) * Q_LW + column + 32
-static_assert(Q_TH * Q_TW <= 0x2000 && Q_TW == 256, "s_ptr packs row << 8 | column into 13 bits");
+constexpr int Q_HOPS = 4;        // hops a tie pixel takes inside k_fin before it is handed to k_tiesx
 constexpr int Q_RS = Q_WW + 3;   // LDS row pitch in words: image words c0/32 - 1 .. c0/32 + Q_WW, + 1 (odd: 11)
 static_assert(Q_TH * Q_WW == Q_NT, "one tile word per thread");
 
@@ -443,16 +439,14 @@ __device__ __forceinline__ void rule_tap(const u32 (&a0)[3], const u32 (&a1)[3],
         if (CODE & (1 << j)) C[j] |= sel;
 }
 
-// the pixels (of 32) whose code planes C spell tap CODE: do they hop onto a tie pixel (T = tie plane of rows -2 .. +2, three
-// words each)?  Their step code (di + 2) << 3 | (dj + 2) goes into the planes E.
+// the pixels (of 32) whose code planes C spell tap CODE: their step code (di + 2) << 3 | (dj + 2) goes into the planes E
 template <int CODE>
-__device__ __forceinline__ void step_tap(const u32 (&C)[4], u32 mytie, const u32 (&T)[5][3], u32 &multi, u32 (&E)[6]) {
+__device__ __forceinline__ void step_tap(const u32 (&C)[4], u32 mytie, u32 (&E)[6]) {
     constexpr int t = CODE & 7;
     constexpr int DI = (CODE & 8) ? -TAP_DI(t) : TAP_DI(t), DJ = (CODE & 8) ? -TAP_DJ(t) : TAP_DJ(t);
     u32 sel = mytie;
 #pragma unroll
     for (int j = 0; j < 4; ++j) sel &= (CODE & (1 << j)) ? C[j] : ~C[j];
-    multi |= sel & qshift<DJ>(T[DI + 2]);
     constexpr int ENC = (DI + 2) << 3 | (DJ + 2);
 #pragma unroll
     for (int j = 0; j < 6; ++j)
@@ -466,8 +460,8 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     float *__restrict__ out_depth, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
     int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres, int vec) {
     __shared__ u32 s_pl[6][Q_TH + 4][Q_RS];  // d bit 0, 1, 2, live, tie, in-image; rows r0-2 .. r0+TH+1
-    __shared__ u8 s_byte[Q_TH][Q_TW];   // per tile pixel: step to its parent ((di + 2) << 3 | (dj + 2); 18 = none) | B_MULTI
-    __shared__ u16 s_ptr[Q_TH * Q_TW];  // per tile pixel: an ancestor on its chain (tile index) | P_TERM | P_EXIT
+    __shared__ u8 s_byte[Q_TH][Q_TW];   // per tile pixel: step to its parent ((di + 2) << 3 | (dj + 2); 18 = none)
+    __shared__ u32 s_unres[Q_NT];       // per tile word: tie pixels that k_tiesx finishes
     __shared__ u32 s_cnt[Q_NT / 64];
     const int b = blockIdx.y, tid = threadIdx.x;
     if (!fflag[b]) return;
@@ -516,11 +510,10 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     }
     __syncthreads();
     const u32 mytie = s_pl[4][trow + 2][tw + 1];
-    u32 left = 0;  // tie pixels of this word that k_tiesx finishes
+    s_unres[tid] = 0;
     const bool any_tie = __syncthreads_or(mytie != 0);  // block-uniform: some tie pixel in this tile
     if (any_tie) {
         u32 C[4] = {0, 0, 0, 0};
-        u32 multi = 0;  // tie pixels whose parent is a tie pixel too (the others end their chain after ONE hop)
         u32 E[6] = {0, ~0u, 0, 0, ~0u, 0};  // bit planes of the step code (di + 2) << 3 | (dj + 2); 18 = (0, 0) where no tie pixel
         // ---- parent rule for this word (planes from LDS: rows trow .. trow + 4 of the window, words tw .. tw + 2)
         if (mytie) {
@@ -557,29 +550,25 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
             rule_tap<-1, 2, false, 8 | 5>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
             rule_tap<-2, 3, false, 8 | 6>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
             rule_tap<+1, 1, false, 8 | 7>(z0, z1, z2, lv, zv, b0, b1, b2, takenB, C);
-            // which tie pixels hop onto another tie pixel, and every tie pixel's step code, still bit-sliced: tap t was
-            // chosen where the code planes spell t
+            // every tie pixel's step code, still bit-sliced: tap t was chosen where the code planes spell t
             {
-                u32 T[5][3];
-#pragma unroll
-                for (int dr = 0; dr < 5; ++dr) ld3(4, trow + dr, T[dr]);
                 E[1] = E[4] = ~mytie;
-                step_tap<0>(C, mytie, T, multi, E);
-                step_tap<1>(C, mytie, T, multi, E);
-                step_tap<2>(C, mytie, T, multi, E);
-                step_tap<3>(C, mytie, T, multi, E);
-                step_tap<4>(C, mytie, T, multi, E);
-                step_tap<5>(C, mytie, T, multi, E);
-                step_tap<6>(C, mytie, T, multi, E);
-                step_tap<7>(C, mytie, T, multi, E);
-                step_tap<8>(C, mytie, T, multi, E);
-                step_tap<9>(C, mytie, T, multi, E);
-                step_tap<10>(C, mytie, T, multi, E);
-                step_tap<11>(C, mytie, T, multi, E);
-                step_tap<12>(C, mytie, T, multi, E);
-                step_tap<13>(C, mytie, T, multi, E);
-                step_tap<14>(C, mytie, T, multi, E);
-                step_tap<15>(C, mytie, T, multi, E);
+                step_tap<0>(C, mytie, E);
+                step_tap<1>(C, mytie, E);
+                step_tap<2>(C, mytie, E);
+                step_tap<3>(C, mytie, E);
+                step_tap<4>(C, mytie, E);
+                step_tap<5>(C, mytie, E);
+                step_tap<6>(C, mytie, E);
+                step_tap<7>(C, mytie, E);
+                step_tap<8>(C, mytie, E);
+                step_tap<9>(C, mytie, E);
+                step_tap<10>(C, mytie, E);
+                step_tap<11>(C, mytie, E);
+                step_tap<12>(C, mytie, E);
+                step_tap<13>(C, mytie, E);
+                step_tap<14>(C, mytie, E);
+                step_tap<15>(C, mytie, E);
             }
         }
         // un-slice into one byte per pixel, four pixels per step: ((nibble * 0x00204081) & 0x01010101) spreads a nibble's
@@ -591,103 +580,12 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
                 u32 v = 0;
 #pragma unroll
                 for (int j = 0; j < 6; ++j) v |= (mul_u24_opaque((E[j] >> (4 * g)) & 0xFu, 0x00204081u) & 0x01010101u) << j;
-                v |= (mul_u24_opaque((multi >> (4 * g)) & 0xFu, 0x00204081u) & 0x01010101u) << 7;  // B_MULTI
                 brow[g] = v;
             }
         }
-        __syncthreads();
-        // ---- the few chains of more than one hop: pointer doubling over the "multi" pixels (any chain length in a few
-        // rounds; a pixel's ancestors are shared by every chain through it).  s_ptr[q] = a pixel further along q's chain;
-        // P_TERM: that pixel is the last tie pixel of the chain inside this tile -- one hop from it ends the chain
-        // (not a tie pixel) or (P_EXIT) leaves the tile onto another tie pixel.
-        {
-            const int qb = trow * Q_TW + tw * 32;
-            const u8 *bflat = &s_byte[0][0];
-            u32 open = 0, m = multi;
-            while (m) {
-                const int k = __ffs((int)m) - 1;
-                m &= m - 1;
-                const int st = bflat[qb + k] & 63;
-                const int pr = trow + (st >> 3) - 2, pc = tw * 32 + k + (st & 7) - 2;
-                u32 v;
-                if (pr < 0 || pr >= Q_TH || pc < 0 || pc >= Q_TW) {
-                    v = (u32)(qb + k) | P_TERM | P_EXIT;
-                } else {
-                    const bool pm = bflat[pr * Q_TW + pc] & B_MULTI;
-                    v = (u32)(pr * Q_TW + pc) | (pm ? 0u : P_TERM);
-                    open |= pm ? 1u << k : 0u;
-                }
-                s_ptr[qb + k] = (u16)v;
-            }
-            __syncthreads();
-            // doubling: any value read is an ancestor (other threads only ever replace a pointer by a farther ancestor)
-            for (int round = 0; round < 16; ++round) {  // 2^16 > any chain inside a tile
-                u32 mm = open;
-                while (mm) {
-                    const int k = __ffs((int)mm) - 1;
-                    mm &= mm - 1;
-                    const u32 a = s_ptr[qb + k];  // no flag: q is open
-                    const u32 pa = s_ptr[a & P_IDX];
-                    s_ptr[qb + k] = (u16)pa;
-                    if (pa & P_TERM) open &= ~(1u << k);
-                }
-                if (!__syncthreads_or(open != 0)) break;
-            }
-            // one hop from the last tie pixel: s_ptr[q] becomes the window position of the pixel whose source q takes
-            // ((row + 2) * Q_LW + column + 32), or P_UNRES if the chain goes on in another tile: q is listed for k_tiesx
-            // with the pixel where it goes on.
-            m = multi;
-            while (m) {
-                const int k = __ffs((int)m) - 1;
-                m &= m - 1;
-                const u32 t = s_ptr[qb + k];
-                const int cr = (int)((t & P_IDX) >> 8), cc = (int)(t & 255u);  // Q_TW == 256
-                const int st = bflat[(t & P_IDX)] & 63;
-                const int er = cr + (st >> 3) - 2, ec = cc + (st & 7) - 2;
-                const bool solved = !(t & P_EXIT);
-                s_ptr[qb + k] = solved ? (u16)((er + 2) * Q_LW + ec + 32) : (u16)P_UNRES;
-                if (!solved) {
-                    const int ei = min(max(r0 + er, 0), H - 1), ej = min(max(c0 + ec, 0), W - 1);  // in the image on consistent planes
-                    left |= 1u << k;
-                    xptr[fo + (u32)(gi * W + gw * 32 + k)] = (u32)(ei * W + ej);
-                }
-            }
-        }
-        // the handed-on pixels join the frame's list: block-wide count, ONE atomic, then every thread writes its own
-        {
-            const int cu = __popc(left);
-            int incl = cu;
-            const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(incl, off);
-                if (lane >= off) incl += t;
-            }
-            if (lane == 63) s_cnt[wave] = (u32)incl;
-            __syncthreads();  // also: s_ptr holds the final positions
-            int pre = 0, all = 0;
-#pragma unroll
-            for (int w = 0; w < Q_NT / 64; ++w) {
-                pre += w < wave ? (int)s_cnt[w] : 0;
-                all += (int)s_cnt[w];
-            }
-            if (all) {  // block-uniform
-                __syncthreads();
-                if (tid == 0) s_cnt[0] = (u32)atomicAdd(&finfo[b * FI_STRIDE + FI_NUNRES], all);
-                __syncthreads();
-                u32 o = s_cnt[0] + (u32)(pre + incl - cu);
-                u32 mm = left;
-                while (mm) {
-                    const int k = __ffs((int)mm) - 1;
-                    mm &= mm - 1;
-                    xlist[fo + o++] = (u32)(gi * W + gw * 32 + k);
-                }
-            }
-        }
     }
-    if (tin) reinterpret_cast<u32 *>(unres + (rowb + gi) * Wp)[gw] = left;
-    // ---- 4. label, depth, stores.  A wave takes one tile row at a time, a lane four consecutive pixels of it: every
-    // load of spix and every store is a run of 1 KB per wave.
+    __syncthreads();  // s_byte is complete (tiles without a tie pixel: not written, not read)
+    // ---- 4. label, depth, stores.  A wave takes tile rows ewave, ewave + waves, ...; a lane four consecutive pixels.
     const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
     const float *x_f = x + fo, *vl_f = vlist + fo;
     const int32_t *lm_f = labelmap + fo;
@@ -696,39 +594,81 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     const u32 lastpix = (u32)(H * W - 1);
     bool bad = false;
     constexpr int NRW = Q_TH / (Q_NT / 64);  // rows per wave (8)
-    // every pixel takes the source k_rows found for the pixel one step along its chain (step (0, 0) unless it is a tie
-    // pixel); the few tie pixels with longer chains take it from the position s_ptr holds
+    // Every pixel takes the source k_rows found for the pixel that ends its chain: itself unless it is a tie pixel; a tie
+    // pixel hops along the step bytes until it stands on a pixel that is not a tie pixel (ONE hop for nine in ten).  A
+    // chain that leaves the tile while still on tie pixels, or is still on one after Q_HOPS hops, is handed to k_tiesx
+    // with the pixel where it goes on (that pixel's own chain is shorter: k_tiesx follows such links to their end).
     u32 esp[NRW][4];
+    u32 umask = 0;  // bit 4 * it + u: handed to k_tiesx
+    auto is_tie = [&](int r, int c) -> bool {  // tile coordinates, ring included
+        return (s_pl[4][r + 2][(c + 32) >> 5] >> ((c + 32) & 31)) & 1u;
+    };
 #pragma unroll
     for (int it = 0; it < NRW; ++it) {
         const int rr = ewave + (Q_NT / 64) * it;
         const int i = r0 + rr;
         const u32 inm = (s_pl[5][rr + 2][lw + 1] >> lb) & 15u;
         const u32 b4 = any_tie ? *reinterpret_cast<const u32 *>(&s_byte[rr][elane * 4]) : 0x12121212u;
-        int pi[4], pj[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const u32 bb = (b4 >> (8 * u)) & 0xFFu;
-            pi[u] = i + (int)((bb >> 3) & 7u) - 2;
-            pj[u] = col + u + (int)(bb & 7u) - 2;
-        }
-        if (b4 & 0x80808080u) {  // rare: a chain of more than one hop
-            const uint2 t4 = *reinterpret_cast<const uint2 *>(&s_ptr[rr * Q_TW + elane * 4]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!((b4 >> (8 * u + 7)) & 1u)) continue;
-                const u32 t = ((u & 2) ? t4.y : t4.x) >> (16 * (u & 1)) & 0xFFFFu;
-                const int wr = (int)(t / Q_LW), wc = (int)(t - (u32)wr * Q_LW);  // window position (a constant division)
-                pi[u] = t == P_UNRES ? i : r0 - 2 + wr;  // handed on: keeps k_rows' source until k_tiesx overwrites it
-                pj[u] = t == P_UNRES ? col + u : c0 - 32 + wc;
+            const u32 bb = (b4 >> (8 * u)) & 63u;
+            int er = rr + (int)(bb >> 3) - 2, ec = elane * 4 + u + (int)(bb & 7u) - 2;  // one hop (none: step (0, 0))
+            if (bb != 18u && is_tie(er, ec)) {  // rare: a chain of more than one hop
+                bool open = true;
+                for (int hop = 1; hop < Q_HOPS; ++hop) {
+                    if (er < 0 || er >= Q_TH || ec < 0 || ec >= Q_TW) break;  // a tie pixel of another tile: no step here
+                    const u32 b2 = s_byte[er][ec] & 63u;
+                    er += (int)(b2 >> 3) - 2;
+                    ec += (int)(b2 & 7u) - 2;
+                    if (!is_tie(er, ec)) {
+                        open = false;
+                        break;
+                    }
+                }
+                if (open) {  // (er, ec) is a tie pixel: keeps k_rows' source until k_tiesx overwrites label and depth
+                    umask |= 1u << (4 * it + u);
+                    const int ei = min(max(r0 + er, 0), H - 1), ej = min(max(c0 + ec, 0), W - 1);
+                    xptr[fo + (u32)(i * W + col + u)] = (u32)(ei * W + ej);
+                    atomicOr(&s_unres[rr * Q_WW + lw], 1u << (lb + u));
+                    er = rr;
+                    ec = elane * 4 + u;
+                }
             }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const u32 off = (u32)(min(max(pi[u], 0), H - 1) * W + min(max(pj[u], 0), W - 1));
+            const u32 off = (u32)(min(max(r0 + er, 0), H - 1) * W + min(max(c0 + ec, 0), W - 1));
             esp[it][u] = ((inm >> u) & 1u) ? ld_off<u32>(sp_f, off << 2) : SPIX_NONE;
         }
     }
+    if (any_tie) {
+        // the handed-on pixels join the frame's list: block-wide count, ONE atomic, then every thread writes its own
+        const int cu = __popc(umask);
+        int incl = cu;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (elane >= off) incl += t;
+        }
+        if (elane == 63) s_cnt[ewave] = (u32)incl;
+        __syncthreads();  // also: s_unres is complete
+        int pre = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < Q_NT / 64; ++w) {
+            pre += w < ewave ? (int)s_cnt[w] : 0;
+            all += (int)s_cnt[w];
+        }
+        if (all) {  // block-uniform
+            __syncthreads();
+            if (tid == 0) s_cnt[0] = (u32)atomicAdd(&finfo[b * FI_STRIDE + FI_NUNRES], all);
+            __syncthreads();
+            u32 o = s_cnt[0] + (u32)(pre + incl - cu);
+            u32 m = umask;
+            while (m) {
+                const int k = __ffs((int)m) - 1;
+                m &= m - 1;
+                xlist[fo + o++] = (u32)((r0 + ewave + (Q_NT / 64) * (k >> 2)) * W + col + (k & 3));
+            }
+        }
+    }
+    if (tin) reinterpret_cast<u32 *>(unres + (rowb + gi) * Wp)[gw] = s_unres[tid];
     // label = labelmap[source], depth = depth_list[label - 1] = x[source] when the masks agree: two gathers per pixel,
     // all 32 pixels of the lane in flight together
     int lab[NRW][4];

@@ -1,14 +1,21 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for bench.py's numbers into gpurun_out/prof_$1/ (run on the GPU box):
-#   kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in two separate --pmc passes
+# Collects the rocprofv3 evidence for bench.py's numbers (run on the GPU box):
+#   for every workload: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in two separate --pmc passes
 #   (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2 -- they do not fit one pass).
-tag=${1:-r01}
-out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
-mkdir -p $out
+# Output: gpurun_out/prof_<tag>/<workload>/{summary.txt,kernel_stats.csv,traffic.json}; copy what is to be judged into profiles/.
+tag=${1:-r02}
+shift
+wls=${@:-kitti_b32 kitti_b32_scanline nyu_b64 synth2048_b16}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/trace.log 2>&1 || exit 1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1 || exit 1
-cd $GRAFT_REPO_ROOT
-python3 scripts/summarize_profile.py $out > $out/summary.txt
-cat $out/summary.txt
+for wl in $wls; do
+  out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag/$wl
+  mkdir -p $out
+  args="--no-cpu-baseline --no-extras --workload $wl"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 $args > $out/trace.log 2>&1 || { echo "trace $wl failed"; tail -3 $out/trace.log; exit 1; }
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $args > $out/pmc_fetch.log 2>&1 || { echo "fetch $wl failed"; exit 1; }
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $args > $out/pmc_write.log 2>&1 || { echo "write $wl failed"; exit 1; }
+  python3 $GRAFT_REPO_ROOT/scripts/summarize_profile.py $out $wl > $out/summary.txt
+  cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+  rm -rf $out/trace $out/pmc_fetch $out/pmc_write
+  cat $out/summary.txt
+done
