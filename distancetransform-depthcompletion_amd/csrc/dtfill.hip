@@ -81,7 +81,7 @@ struct Carve {
     u32 *xlist, *xptr;   // k_fin -> k_tiesx: the pixels whose chain left their tile, and where each goes on
     u32 *spix;           // k_rows -> k_fin: per pixel, the frame offset of its nearest source in column kmin
     int32_t *labelmap;   // k_labels: at every source pixel, its label (1 + raster rank among the frame's sources)
-    int *finfo, *fflag2, *status;
+    int *finfo, *fflag2, *route, *status;
     float *vlist;
     size_t total;
 };
@@ -109,6 +109,7 @@ Carve carve(void *ws, int B, int H, int W) {
     c.rowbase_v = (u32 *)take(NR * 4);
     c.finfo = (int *)take((size_t)B * FI_STRIDE * 4);
     c.fflag2 = (int *)take((size_t)B * 4);
+    c.route = (int *)take((size_t)B * 4);
     c.status = (int *)take((size_t)B * 4);
     // any-distance path (touched only for frames the fused kernel does not take)
     c.nb = (H + 31) / 32;
@@ -162,17 +163,25 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s,
-                               c.rowbase_v, c.finfo, c.vlist, c.fflag2, status, general_only ? 1 : 0);
+                               c.rowbase_v, c.finfo, c.vlist, c.fflag2, c.route, status, general_only ? 1 : 0);
     mark();
     if (!general_only) {
-        // dense frames: one window kernel (halo 16).  It hands a frame on (fflag2) when the frame is too sparse for
-        // the halo or a tile pixel turns out to be farther than 16 from every source.
-        constexpr int R = 16, THM = F_WHM - 2 * R, TWM = F_WWM - 2 * R;
-        const int nty = (H + THM - 1) / THM, ntx = (W + TWM - 1) / TWM;
-        const int TH = (H + nty - 1) / nty, TW = (W + ntx - 1) / ntx;  // even split
-        k_fused<R><<<dim3(ntx * nty, B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd,
-                                                       TH, TW, ntx, out_depth, out_dt, out_index, c.fflag2,
-                                                       status);
+        // dense frames: the window kernel, halo 16 or 32 per frame (k_frame's route).  It hands a frame on (fflag2) when a
+        // tile pixel turns out to be farther than the halo from every source.
+        auto tiling = [&](int R) {
+            const int THM = F_WHM - 2 * R, TWM = F_WWM - 2 * R;
+            const int nty = (H + THM - 1) / THM, ntx = (W + TWM - 1) / TWM;
+            FusedTiles t;
+            t.TH = (H + nty - 1) / nty;  // even split
+            t.TW = (W + ntx - 1) / ntx;
+            t.tiles_x = ntx;
+            t.ntiles = ntx * nty;
+            return t;
+        };
+        const FusedTiles t16 = tiling(16), t32 = tiling(32);
+        k_fused<<<dim3(max(t16.ntiles, t32.ntiles), B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W,
+                                                                      Wd, t16, t32, out_depth, out_dt, out_index, c.route,
+                                                                      c.fflag2, status);
     }
     mark();
     if (!fused_only) {
@@ -241,7 +250,7 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
-                               c.finfo, c.vlist, c.fflag2, status, 0);
+                               c.finfo, c.vlist, c.fflag2, c.route, status, 0);
     mark();
     {
         const int cw = min(16, max(2, (c.nb + 1) / 2));

@@ -247,28 +247,19 @@ __device__ __forceinline__ bool fused_walk_epilogue(
 }
 
 // FR = halo = largest distance the window can decide.
-// are processed (the second, FR = 32 stage only redoes the frames the FR = 16 stage flagged).
+// Geometry of one halo's tiling (host side computes it; the window is always F_WHM x F_WWM)
+struct FusedTiles {
+    int TH, TW, tiles_x, ntiles;
+};
+
 template <int FR>
-__global__ __launch_bounds__(F_NT, 4) void k_fused(
+__device__ __forceinline__ void fused_body(
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
     int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
     float *__restrict__ out_dt, int32_t *__restrict__ out_index,
-    int *__restrict__ fflag, int *__restrict__ frame_status) {
-    if (fflag[blockIdx.y]) return;  // the any-distance kernels take this frame (k_frame's choice)
-    // Speed heuristic only (never correctness): with source density p the chance that a pixel has no source
-    // within L1 distance FR is about (1-p)^(2 FR^2 + 2 FR + 1); if the frame is expected to hold such a pixel
-    // anyway (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), this stage would only flag the frame after doing
-    // all the work -- hand it on right away.  Likewise when k_frame found a run of source-free rows that forces
-    // some distance above FR (real LiDAR frames: the empty sky rows).  (The two finfo loads are issued together
-    // with the window loads below; the branch comes after those are in flight.)
-    __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
-    // per window row, the eight image-aligned 32-pixel half words it touches: {source bits, sources before them
-    // in frame raster order} -- one 8-byte LDS read and a 32-bit popcount per rank lookup
-    __shared__ uint2 s_rw[F_WHM * 8];
-    __shared__ short s_tab[64];      // s_par displacement of the step enc (0 for the codes that are no step)
-    __shared__ u32 s_any[2][F_NT / 64];  // per wave: did level t produce anything (double-buffered by level parity)
-
+    int *__restrict__ fflag, int *__restrict__ frame_status, u32 *__restrict__ s_ring, uint2 *__restrict__ s_rw,
+    short *__restrict__ s_tab, u32 (*__restrict__ s_any)[F_NT / 64]) {
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -499,5 +490,33 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     if (overflow) {
         fflag[b] = 1;  // same-value race: every writer stores 1, the any-distance kernels read it after this kernel
         atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);
+    }
+}
+
+// k_fused: one launch for both halos.  route[b] (k_frame): 16 / 32 = the halo that is expected to decide every pixel of
+// frame b (source density, runs of source-free rows), 0 = the any-distance kernels take the frame.  The grid is
+// sized for the halo-32 tiling (more, smaller tiles); blocks beyond a frame's own tiling exit.  A frame in which a
+// tile pixel turns out to be farther than the halo is handed to the any-distance kernels (fflag, frame_status).
+__global__ __launch_bounds__(F_NT, 4) void k_fused(
+    const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
+    const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
+    int H, int W, int Wd, FusedTiles t16, FusedTiles t32, float *__restrict__ out_depth,
+    float *__restrict__ out_dt, int32_t *__restrict__ out_index,
+    const int *__restrict__ route, int *__restrict__ fflag, int *__restrict__ frame_status) {
+    __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
+    // per window row, the eight image-aligned 32-pixel half words it touches: {source bits, sources before them
+    // in frame raster order} -- one 8-byte LDS read and a 32-bit popcount per rank lookup
+    __shared__ uint2 s_rw[F_WHM * 8];
+    __shared__ short s_tab[64];      // s_par displacement of the step enc (0 for the codes that are no step)
+    __shared__ u32 s_any[2][F_NT / 64];  // per wave: did level t produce anything (double-buffered by level parity)
+    const int r = route[blockIdx.y];  // block-uniform
+    if (r == 16) {
+        if ((int)blockIdx.x < t16.ntiles)
+            fused_body<16>(x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, t16.TH, t16.TW, t16.tiles_x, out_depth, out_dt,
+                           out_index, fflag, frame_status, s_ring, s_rw, s_tab, s_any);
+    } else if (r == 32) {
+        if ((int)blockIdx.x < t32.ntiles)
+            fused_body<32>(x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, t32.TH, t32.TW, t32.tiles_x, out_depth, out_dt,
+                           out_index, fflag, frame_status, s_ring, s_rw, s_tab, s_any);
     }
 }

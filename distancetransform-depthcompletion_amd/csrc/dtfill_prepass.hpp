@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
                                                u32 *__restrict__ rowbase_s, u32 *__restrict__ rowbase_v,
                                                int *__restrict__ finfo, float *__restrict__ vlist,
                                                int *__restrict__ fflag2,
-                                               int *__restrict__ frame_status, int mode) {
+                                               int *__restrict__ route, int *__restrict__ frame_status, int mode) {
     const bool force_general = mode & 1;  // every frame takes the any-distance kernels (tests)
     __shared__ u32 s_ws[4], s_wv[4];
     __shared__ int s_mis, s_dlb;
@@ -276,12 +276,15 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         finfo[b * FI_STRIDE + FI_NUNRES] = 0;
         // Which kernel family takes the frame -- a speed heuristic, never a correctness condition (the window kernel
         // itself hands on every frame in which it meets a pixel it cannot decide).  With source density p the chance
-        // that a pixel has no source within L1 distance 16 is about (1-p)^545; if the frame is expected to hold such
-        // a pixel anyway (N (1-p)^545 > ~1, i.e. p * 545 < ln N ~ 14), or a run of source-free rows forces a distance
-        // above 16 (real LiDAR frames: the empty sky rows), the window kernel would only find that out after doing
-        // all its work: the any-distance kernels take the frame right away.
-        const bool sparse = (long long)run_s * (2 * 16 * 16 + 2 * 16 + 1) < 14ll * H * W || s_dlb > 16;
-        const bool general = force_general || sparse;
+        // that a pixel has no source within L1 distance R is about (1-p)^(2 R^2 + 2 R + 1); if the frame is expected to
+        // hold such a pixel anyway (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), or a run of source-free rows forces
+        // a distance above R (real LiDAR frames: the empty sky rows), a window kernel with halo R would only find
+        // that out after doing all its work.  route: halo 16 if it fits, else halo 32 (three times the work per pixel,
+        // still cheaper than the any-distance kernels at a few percent density), else the any-distance kernels.
+        auto fits = [&](int R) { return (long long)run_s * (2 * R * R + 2 * R + 1) >= 14ll * H * W && s_dlb <= R; };
+        const int r = force_general ? 0 : fits(16) ? 16 : fits(32) ? 32 : 0;
+        route[b] = r;
+        const bool general = r == 0;
         fflag2[b] = general ? 1 : 0;  // also set by k_fused when it meets a pixel farther than its halo
         frame_status[b] = general ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
     }

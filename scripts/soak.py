@@ -11,16 +11,31 @@ rng = np.random.default_rng(seed)
 op = pkg.device.DtFill(device="cuda:0"); op2 = pkg.device.DtFill(device="cuda:0", metric="l2")
 bad = 0; t0 = time.time(); npx = 0
 for t in range(n):
-    kind = t % 4
+    kind = t % 6
     if kind == 0:   # KITTI-size, densities around the fused halos' limits
         B, H, W = 2, 352, 1216; p = float(rng.choice([0.008, 0.015, 0.03, 0.05, 0.1]))
     elif kind == 1:
         B, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 500)), int(rng.integers(1, 900)); p = float(rng.choice([0.002, 0.02, 0.06, 0.3]))
     elif kind == 2:  # tile-seam sizes
         B, H, W = 1, int(rng.choice([87, 88, 89, 95, 96, 97, 176, 192])), int(rng.choice([151, 152, 153, 159, 160, 161, 304, 320])); p = 0.05
-    else:
+    elif kind == 3:
         B, H, W = 3, 240, 320; p = float(rng.choice([0.001, 0.005, 0.05]))
+    elif kind == 4:  # a handful of points: long distances, long tie chains (diagonal pairs make whole quadrants tie)
+        B, H, W = 2, int(rng.integers(40, 400)), int(rng.integers(40, 700)); p = 0.0
+    else:            # LiDAR rings: sources on every 4th row below an empty sky
+        B, H, W = 2, 352, int(rng.choice([1216, 1242, 640])); p = 0.25
     x = np.where(rng.random((B, H, W)) < p, rng.uniform(0.95, 80, (B, H, W)), 0).astype(np.float32)
+    if kind == 4:
+        for bb in range(B):
+            for _ in range(int(rng.integers(1, 30))):
+                i, j = int(rng.integers(0, H)), int(rng.integers(0, W))
+                x[bb, i, j] = rng.uniform(1, 80)
+                if rng.random() < 0.5:  # a partner on an exact diagonal
+                    k = int(rng.integers(1, 40)); sgn = int(rng.choice([-1, 1]))
+                    if 0 <= i + k < H and 0 <= j + sgn * k < W: x[bb, i + k, j + sgn * k] = rng.uniform(1, 80)
+    if kind == 5:
+        rows = np.zeros(H, bool); rows[int(rng.integers(60, 140))::4] = True
+        x *= rows[None, :, None]
     if rng.random() < 0.4:
         a, b_ = sorted(rng.integers(0, H + 1, 2)); x[:, a:b_] *= (rng.random((B, 1, 1)) < 0.5)
     if rng.random() < 0.3:
