@@ -29,6 +29,7 @@ SYMBOLS = (
     "dtfill_workspace_bytes",
     "dtfill_batch",
     "dtfill_batch_flags",
+    "dtfill_batch_epilogue",
     "dtfill_num_kernels",
     "dtfill_kernel_name",
     "dtfill_batch_timed",
@@ -86,6 +87,8 @@ def load():
     L.dtfill_batch.restype = ci
     L.dtfill_batch_flags.argtypes = [vp, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, sz, vp, ctypes.c_uint]
     L.dtfill_batch_flags.restype = ci
+    L.dtfill_batch_epilogue.argtypes = [vp, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, sz, vp, ctypes.c_uint, ci, ci, cf]
+    L.dtfill_batch_epilogue.restype = ci
     L.dtfill_num_kernels.argtypes = [ci]
     L.dtfill_num_kernels.restype = ci
     L.dtfill_kernel_name.argtypes = [ci, ci]

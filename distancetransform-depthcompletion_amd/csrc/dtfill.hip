@@ -79,6 +79,7 @@ struct Carve {
                          // from the band's first / last row to the nearest source above / below}; rows of ctp columns
     int nb, ctp;         // bands per frame, columns per row of ct
     u32 *xlist, *xptr;   // k_fin -> k_tiesx: the pixels whose chain left their tile, and where each goes on
+    float *dscratch;     // k_fin -> k_tiesx: depths of the rows a depth epilogue drops from the output
     u32 *spix;           // k_rows -> k_fin: per pixel, the frame offset of its nearest source in column kmin
     int32_t *labelmap;   // k_labels: at every source pixel, its label (1 + raster rank among the frame's sources)
     int *finfo, *fflag2, *route, *status;
@@ -117,6 +118,7 @@ Carve carve(void *ws, int B, int H, int W) {
     c.ct = (uint2 *)take((size_t)B * c.nb * c.ctp * sizeof(uint2));
     c.labelmap = (int32_t *)take(N * 4);
     c.spix = (u32 *)take(N * 4);
+    c.dscratch = (float *)take(N * 4);
     c.xlist = (u32 *)take(N * 4);
     c.xptr = (u32 *)take(N * 4);
     c.plane_bytes = align256(NW * 8);
@@ -147,7 +149,7 @@ void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, flo
 
 int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, float *out_depth,
            float *out_dt, int32_t *out_index, int32_t *frame_status, void *workspace, unsigned flags,
-           hipStream_t st, hipEvent_t *ev) {
+           hipStream_t st, hipEvent_t *ev, DepthEpilogue ep = DepthEpilogue{0, 0, 0.0f}) {
     const Carve c = carve(workspace, B, H, W);
     const int Wd = (W + 63) / 64;
     int *status = frame_status ? frame_status : c.status;
@@ -181,7 +183,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const FusedTiles t16 = tiling(16), t32 = tiling(32);
         k_fused<<<dim3(max(t16.ntiles, t32.ntiles), B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W,
                                                                       Wd, t16, t32, out_depth, out_dt, out_index, c.route,
-                                                                      c.fflag2, status);
+                                                                      c.fflag2, status, ep);
     }
     mark();
     if (!fused_only) {
@@ -219,10 +221,10 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
             const int vec = (W & 3) == 0 && aligned(out_depth, 16) && aligned(out_index, 16);
             k_fin<<<dim3(ttx * tty, B), Q_NT, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, Wd, ttx, c.spix, x, c.labelmap,
                                                        c.vlist, out_depth, out_index, status, c.finfo,
-                                                       c.xlist, c.xptr, c.planes + PL_UNRES * c.plane_bytes, vec);
+                                                       c.xlist, c.xptr, c.planes + PL_UNRES * c.plane_bytes, vec, ep, c.dscratch);
             mark();
             k_tiesx<<<dim3(XL_BLOCKS, B), 256, 0, st>>>(c.planes + PL_UNRES * c.plane_bytes, Wp, c.fflag2, c.finfo, c.xlist,
-                                                        c.xptr, H, W, out_depth, out_index);
+                                                        c.xptr, H, W, out_depth, out_index, ep, c.dscratch);
             mark();
         } else {
             mark();
@@ -316,6 +318,18 @@ int dtfill_batch(const float *x, int B, int H, int W, float src_thr, float val_t
                  void *workspace, size_t ws_bytes, void *stream) {
     return dtfill_batch_flags(x, B, H, W, src_thr, val_thr, metric, out_depth, out_dt, out_index,
                               frame_status, workspace, ws_bytes, stream, 0u);
+}
+
+int dtfill_batch_epilogue(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
+                          float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
+                          void *workspace, size_t ws_bytes, void *stream, unsigned flags, int depth_row0, int use_floor,
+                          float floor_) {
+    int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes);
+    if (rc != DTFILL_OK) return rc;
+    if (depth_row0 < 0 || depth_row0 >= H) return DTFILL_ERR_SHAPE;
+    if (metric != DTFILL_METRIC_L1_CV) return (depth_row0 || use_floor) ? DTFILL_ERR_METRIC : dtfill_batch_flags(x, B, H, W, src_thr, val_thr, metric, out_depth, out_dt, out_index, frame_status, workspace, ws_bytes, stream, flags);
+    return run_l1(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags,
+                  static_cast<hipStream_t>(stream), nullptr, DepthEpilogue{depth_row0, use_floor ? 1 : 0, floor_});
 }
 
 int dtfill_outlier_removal(const float *x, int B, int H, int W, float *out, void *stream) {

@@ -29,3 +29,15 @@ __device__ __forceinline__ void tap_decode(int code, int &di, int &dj) {
     }
 }
 
+
+// What the reference's drivers do to the filled depth right after the fill, folded into the depth stores:
+// rows [row0, H) only (demo.py:292-293: lidar_batch[:, 96:]) and / or the depth floor relu(d - floor) + floor in
+// float32 with both roundings (eval_NYU.py:205, test.py:133).  out_depth is then [B, H - row0, W].
+struct DepthEpilogue {
+    int row0;
+    int use_floor;
+    float floor_;
+};
+__device__ __forceinline__ float depth_epilogue(float d, const DepthEpilogue &ep) {
+    return ep.use_floor ? __fadd_rn(fmaxf(__fsub_rn(d, ep.floor_), 0.0f), ep.floor_) : d;
+}

@@ -117,13 +117,13 @@ __device__ __forceinline__ void ring_store3(u32 *__restrict__ ring, int slot, in
 // P3 of the fused pass as a function of the staged window (s_par byte codes, s_rw rank half words): tile
 // pixels walk to their sources in lock-step, d, rank -> label, gather, store.  Returns whether some tile pixel
 // was undecided.  NT = threads of the calling block.
-template <int FR, int NT>
+template <int FR, int NT, bool EPI>
 __device__ __forceinline__ bool fused_walk_epilogue(
     const u8 *__restrict__ s_par, const short *__restrict__ s_tab, const uint2 *__restrict__ s_rw, int b, int H,
     int W, int th, int tw, int r0, int c0, int wr0, int wc0, int sh, const float *__restrict__ x,
     const float *__restrict__ vlist,
     const int *__restrict__ finfo, float *__restrict__ out_depth, float *__restrict__ out_dt,
-    int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
+    int32_t *__restrict__ out_index, int *__restrict__ frame_status, const DepthEpilogue ep) {
     // ---- P3: tile pixels: walk to the source, d, rank -> label, gather, store.  Each lane walks F_EB
     // pixels in lock-step (their LDS reads are independent, so the hop latencies overlap) and then has
     // F_EB global gathers in flight together.
@@ -132,7 +132,10 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     const int nval = finfo[b * FI_STRIDE + FI_NVAL];
     const int misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
     const float *gbase = misaligned ? vlist + fo : x + fo;
-    float *od = out_depth ? out_depth + fo : nullptr, *ot = out_dt ? out_dt + fo : nullptr;
+    // the depth output may drop the first ep.row0 rows (then frames are H - row0 rows apart)
+    float *od = out_depth ? out_depth + (size_t)b * (H - ep.row0) * W : nullptr, *ot = out_dt ? out_dt + fo : nullptr;
+    const u32 dcrop = (u32)(ep.row0 * W) << 2;  // bytes of a frame's dropped rows
+    constexpr bool plain = !EPI;  // the plain pass is compiled without the epilogue
     int32_t *oi = out_index ? out_index + fo : nullptr;
     const char *tab = reinterpret_cast<const char *>(s_tab);
     const int src_base = wr0 * W + wc0;  // frame offset of window cell (0,0) (may be negative)
@@ -155,7 +158,11 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             // p_opix is a BYTE offset (< 2^32: a frame has < 2^26 pixels): scalar base + 32-bit vector offset
             if (oi) *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(oi) + p_opix[e]) = p_lab[e];
             if (ot) *reinterpret_cast<float *>(reinterpret_cast<char *>(ot) + p_opix[e]) = (float)p_dd[e];
-            if (od) *reinterpret_cast<float *>(reinterpret_cast<char *>(od) + p_opix[e]) = p_val[e];
+            if (od && plain) {
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(od) + p_opix[e]) = p_val[e];
+            } else if (od && p_opix[e] >= dcrop) {  // block-uniform choice: the plain pass pays nothing for the epilogue
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(od) + (p_opix[e] - dcrop)) = depth_epilogue(p_val[e], ep);
+            }
         }
     };
     for (int pb = 0; pb < npx; pb += NT * F_EB) {
@@ -252,13 +259,13 @@ struct FusedTiles {
     int TH, TW, tiles_x, ntiles;
 };
 
-template <int FR>
+template <int FR, bool EPI>
 __device__ __forceinline__ void fused_body(
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
     int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
     float *__restrict__ out_dt, int32_t *__restrict__ out_index,
-    int *__restrict__ fflag, int *__restrict__ frame_status, u32 *__restrict__ s_ring, uint2 *__restrict__ s_rw,
+    int *__restrict__ fflag, int *__restrict__ frame_status, const DepthEpilogue ep, u32 *__restrict__ s_ring, uint2 *__restrict__ s_rw,
     short *__restrict__ s_tab, u32 (*__restrict__ s_any)[F_NT / 64]) {
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -485,8 +492,8 @@ __device__ __forceinline__ void fused_body(
     }
     __syncthreads();
 
-    const bool overflow = fused_walk_epilogue<FR, F_NT>(s_par, s_tab, s_rw, b, H, W, th, tw, r0, c0, wr0, wc0, sh, x, vlist,
-                                                        finfo, out_depth, out_dt, out_index, frame_status);
+    const bool overflow = fused_walk_epilogue<FR, F_NT, EPI>(s_par, s_tab, s_rw, b, H, W, th, tw, r0, c0, wr0, wc0, sh, x, vlist,
+                                                        finfo, out_depth, out_dt, out_index, frame_status, ep);
     if (overflow) {
         fflag[b] = 1;  // same-value race: every writer stores 1, the any-distance kernels read it after this kernel
         atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);
@@ -502,21 +509,28 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
     int H, int W, int Wd, FusedTiles t16, FusedTiles t32, float *__restrict__ out_depth,
     float *__restrict__ out_dt, int32_t *__restrict__ out_index,
-    const int *__restrict__ route, int *__restrict__ fflag, int *__restrict__ frame_status) {
+    const int *__restrict__ route, int *__restrict__ fflag, int *__restrict__ frame_status, const DepthEpilogue ep) {
     __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
     // per window row, the eight image-aligned 32-pixel half words it touches: {source bits, sources before them
     // in frame raster order} -- one 8-byte LDS read and a 32-bit popcount per rank lookup
     __shared__ uint2 s_rw[F_WHM * 8];
     __shared__ short s_tab[64];      // s_par displacement of the step enc (0 for the codes that are no step)
     __shared__ u32 s_any[2][F_NT / 64];  // per wave: did level t produce anything (double-buffered by level parity)
-    const int r = route[blockIdx.y];  // block-uniform
-    if (r == 16) {
-        if ((int)blockIdx.x < t16.ntiles)
-            fused_body<16>(x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, t16.TH, t16.TW, t16.tiles_x, out_depth, out_dt,
-                           out_index, fflag, frame_status, s_ring, s_rw, s_tab, s_any);
-    } else if (r == 32) {
-        if ((int)blockIdx.x < t32.ntiles)
-            fused_body<32>(x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, t32.TH, t32.TW, t32.tiles_x, out_depth, out_dt,
-                           out_index, fflag, frame_status, s_ring, s_rw, s_tab, s_any);
+    const int r = route[blockIdx.y];         // block-uniform
+    const bool epi = ep.row0 != 0 || ep.use_floor;  // uniform: the plain pass runs code compiled without the epilogue
+#define FUSED_CALL(FR_, EPI_, T_)                                                                                        \
+    fused_body<FR_, EPI_>(x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, T_.TH, T_.TW, T_.tiles_x, out_depth, out_dt, \
+                          out_index, fflag, frame_status, ep, s_ring, s_rw, s_tab, s_any)
+    if (r == 16 && (int)blockIdx.x < t16.ntiles) {
+        if (epi)
+            FUSED_CALL(16, true, t16);
+        else
+            FUSED_CALL(16, false, t16);
+    } else if (r == 32 && (int)blockIdx.x < t32.ntiles) {
+        if (epi)
+            FUSED_CALL(32, true, t32);
+        else
+            FUSED_CALL(32, false, t32);
     }
+#undef FUSED_CALL
 }

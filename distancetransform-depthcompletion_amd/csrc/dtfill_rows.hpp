@@ -458,7 +458,8 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     int tiles_x, const u32 *__restrict__ spix_ws, const float *__restrict__ x, const int32_t *__restrict__ labelmap,
     const float *__restrict__ vlist,
     float *__restrict__ out_depth, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
-    int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres, int vec) {
+    int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres, int vec,
+    const DepthEpilogue ep, float *__restrict__ dscratch) {
     __shared__ u32 s_pl[6][Q_TH + 4][Q_RS];  // d bit 0, 1, 2, live, tie, in-image; rows r0-2 .. r0+TH+1
     __shared__ u8 s_byte[Q_TH][Q_TW];   // per tile pixel: step to its parent ((di + 2) << 3 | (dj + 2); 18 = none)
     __shared__ u32 s_unres[Q_NT];       // per tile word: tie pixels that k_tiesx finishes
@@ -589,7 +590,11 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
     const float *x_f = x + fo, *vl_f = vlist + fo;
     const int32_t *lm_f = labelmap + fo;
-    float *dp_f = out_depth ? out_depth + fo : nullptr;
+    // the depth output may drop the first ep.row0 rows (frames are then H - row0 rows apart); the depths of the dropped
+    // rows go to a scratch frame instead, where k_tiesx finds them if a handed-on chain ends there
+    float *dp_f = out_depth ? out_depth + (size_t)b * (H - ep.row0) * W : nullptr;
+    float *ds_f = dscratch + fo;
+    const u32 dcrop = (u32)(ep.row0 * W) << 2;
     int32_t *ix_f = out_index ? out_index + fo : nullptr;
     const u32 lastpix = (u32)(H * W - 1);
     bool bad = false;
@@ -705,15 +710,22 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
                 val[it][u] = oob ? nanf("") : ((misaligned || none) ? vl_f[idx] : val[it][u]);
             }
         }
+        const bool kept = pixb >= dcrop;  // wave-uniform: a wave holds one row
+        if (dp_f && kept) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) val[it][u] = depth_epilogue(val[it][u], ep);
+        }
+        float *dst = kept ? dp_f : ds_f;
+        const u32 dpix = kept ? pixb - dcrop : pixb;
         if (vec && inm == 15u) {
             if (ix_f) st_off(ix_f, pixb, make_int4(lab[it][0], lab[it][1], lab[it][2], lab[it][3]));
-            if (dp_f) st_off(dp_f, pixb, make_float4(val[it][0], val[it][1], val[it][2], val[it][3]));
+            if (dp_f) st_off(dst, dpix, make_float4(val[it][0], val[it][1], val[it][2], val[it][3]));
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (!((inm >> u) & 1u)) continue;
                 if (ix_f) st_off(ix_f, pixb + 4 * u, lab[it][u]);
-                if (dp_f) st_off(dp_f, pixb + 4 * u, val[it][u]);
+                if (dp_f) st_off(dst, dpix + 4 * u, val[it][u]);
             }
         }
     }
@@ -733,15 +745,19 @@ constexpr int XL_BLOCKS = 16;  // blocks per frame (grid-stride over the list)
 __global__ __launch_bounds__(256) void k_tiesx(const u8 *__restrict__ unres, int Wp, const int *__restrict__ fflag,
                                                const int *__restrict__ finfo, const u32 *__restrict__ xlist,
                                                const u32 *__restrict__ xptr, int H, int W, float *out_depth,
-                                               int32_t *out_index) {
+                                               int32_t *out_index, const DepthEpilogue ep,
+                                               const float *__restrict__ dscratch) {
     const int b = blockIdx.y;
     if (!fflag[b]) return;
     const int n = finfo[b * FI_STRIDE + FI_NUNRES];
     const size_t rowb = (size_t)b * H;
     const size_t fo = (size_t)b * H * W;
     const int32_t *__restrict__ rd_i = out_index;  // reads: finished pixels; writes: listed pixels
-    const float *__restrict__ rd_f = out_depth;
     int32_t *__restrict__ wr_i = out_index;
+    // depth output: rows [ep.row0, H) of every frame; the finished pixels of the dropped rows keep theirs in dscratch
+    const size_t fod = (size_t)b * (H - ep.row0) * W;
+    const u32 dcrop = (u32)(ep.row0 * W);
+    const float *__restrict__ rd_f = out_depth;
     float *__restrict__ wr_f = out_depth;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += XL_BLOCKS * 256) {
         const u32 q = xlist[fo + e];
@@ -754,6 +770,7 @@ __global__ __launch_bounds__(256) void k_tiesx(const u8 *__restrict__ unres, int
             p = min(nx, (u32)(H * W - 1));
         }
         if (out_index) wr_i[fo + q] = rd_i[fo + p];
-        if (out_depth) wr_f[fo + q] = rd_f[fo + p];
+        if (out_depth && q >= dcrop)
+            wr_f[fod + q - dcrop] = p >= dcrop ? rd_f[fod + p - dcrop] : depth_epilogue(dscratch[fo + p], ep);
     }
 }

@@ -63,12 +63,14 @@ class DtFill:
         return int(self.lib.dtfill_workspace_bytes(B, H, W, self.metric))
 
     # -- the op --------------------------------------------------------------------------------
-    def run(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL, timed=False, path="auto"):
+    def run(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL, timed=False, path="auto", depth_rows_from=0, depth_floor=None):
         """x: float32 CUDA tensor [B,H,W] (contiguous).  Returns a dict of device tensors
         (views of buffers owned by this object, overwritten by the next call) for the names in
         `want`, plus "status" (int32 [B], bit set of _lib.FRAME_*).  Asynchronous on the current
-        stream unless timed.  path: "auto" (fused LDS-tile kernel, general kernels for frames it
-        flags), "general" or "fused" (tests / benchmarks)."""
+        stream unless timed.  path: "auto" (window kernel for dense frames, any-distance kernels for the
+        others), "general" or "fused" (tests / benchmarks).  depth_rows_from / depth_floor: the drivers'
+        post-fill steps folded into the depth stores (demo.py:292-293 rows 96:, eval_NYU.py:205
+        relu(d - 0.9) + 0.9): "depth" is then [B, H - depth_rows_from, W]; l1_cv only."""
         if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 3 or not x.is_contiguous():
             raise ValueError("x must be a contiguous float32 CUDA tensor [B,H,W]")
         B, H, W = x.shape
@@ -77,6 +79,13 @@ class DtFill:
                 raise ValueError("x lives on %s, operator on %s" % (x.device, self.device))
             self._ensure(B, H, W)
             o = self._out
+            epi = depth_rows_from != 0 or depth_floor is not None
+            if epi:
+                if timed or not (0 <= depth_rows_from < H):
+                    raise ValueError("depth epilogue: 0 <= depth_rows_from < H, and not with timed=True")
+                if getattr(self, "_crop", None) is None or self._crop.shape != (B, H - depth_rows_from, W):
+                    self._crop = torch.empty((B, H - depth_rows_from, W), dtype=torch.float32, device=self.device)
+                o = dict(o, depth=self._crop)
             ptr = lambda name: o[name].data_ptr() if name in want else None
             stream = torch.cuda.current_stream(self.device).cuda_stream
             args = [
@@ -91,13 +100,16 @@ class DtFill:
                 _lib.check(self.lib.dtfill_batch_timed(*args, flags, ctypes.cast(ms, ctypes.c_void_p)))
                 names = [self.lib.dtfill_kernel_name(self.metric, k).decode() for k in range(nk)]
                 self.last_kernel_ms = dict(zip(names, [float(v) for v in ms]))
+            elif epi:
+                _lib.check(self.lib.dtfill_batch_epilogue(*args, flags, int(depth_rows_from), int(depth_floor is not None),
+                                                          float(depth_floor or 0.0)))
             else:
                 _lib.check(self.lib.dtfill_batch_flags(*args, flags))
         res = {k: o[k] for k in want}
         res["status"] = o["status"]
         return res
 
-    def run_numpy(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL):
+    def run_numpy(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL, depth_rows_from=0, depth_floor=None):
         """numpy in / numpy out: H2D, run, D2H.  x: float32 [B,H,W].  Raises IndexError exactly
         where numpy would in depth_list[label_list-1] (tools.py:26) when depth is wanted.
         The transfers go through pinned staging buffers kept per shape (the returned arrays are fresh
@@ -120,11 +132,11 @@ class DtFill:
         np.copyto(self._pin_in.numpy(), xh, casting="same_kind")  # one pass: gathers strided input, casts if needed
         with torch.cuda.device(self.device):
             self._dev_in.copy_(self._pin_in, non_blocking=True)
-            res = self.run(self._dev_in, src_thr, val_thr, want)
+            res = self.run(self._dev_in, src_thr, val_thr, want, depth_rows_from=depth_rows_from, depth_floor=depth_floor)
             for k, v in res.items():
-                self._pin_out[k].copy_(v, non_blocking=True)
+                self._pin_out[k][:, : v.shape[1]].copy_(v, non_blocking=True) if v.dim() == 3 else self._pin_out[k].copy_(v, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
-        out = {k: self._pin_out[k].numpy().copy() for k in res}
+        out = {k: (self._pin_out[k][:, : res[k].shape[1]] if res[k].dim() == 3 else self._pin_out[k]).numpy().copy() for k in res}
         if "depth" in want:
             bad = np.nonzero(out["status"] & _lib.FRAME_INDEX_ERROR)[0]
             if bad.size:

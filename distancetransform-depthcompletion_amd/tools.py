@@ -41,20 +41,24 @@ def nearest_point(refined_lidar, src_thr=0.1):
     return out["dt"][0], out["index"][0]
 
 
-def DT_complete_batch(lidar_batch, src_thr=0.1, val_thr=0.1):
+def DT_complete_batch(lidar_batch, src_thr=0.1, val_thr=0.1, first_row=0, floor=None):
     """tools.py:13-35.  lidar_batch [B,H,W,C>=1] (channel 0 is used, tools.py:18) ->
-    float32 [B,H,W,1].  Raises IndexError like tools.py:26 when a frame's value list is too short."""
+    float32 [B,H,W,1].  Raises IndexError like tools.py:26 when a frame's value list is too short.
+    first_row / floor fold the caller's next lines into the same pass: demo.py:292-293
+    (lidar_batch[:, 96:, :, :] -> first_row=96, result [B,H-96,W,1]) and the depth floor relu(d - 0.9) + 0.9."""
     lb = _as_f32_frames(lidar_batch)
     if lb.ndim != 4:
         raise IndexError("too many indices for array: DT_complete_batch indexes lidar_batch[i,:,:,0]")
     x = lb[:, :, :, 0]
-    out = _device.default_op().run_numpy(x, src_thr=src_thr, val_thr=val_thr, want=("depth",))
+    out = _device.default_op().run_numpy(x, src_thr=src_thr, val_thr=val_thr, want=("depth",), depth_rows_from=first_row,
+                                         depth_floor=floor)
     return np.expand_dims(out["depth"], axis=-1)  # already a fresh float32 array
 
 
-def Distance_Transform(lidar, src_thr=0.001, val_thr=0.1):
+def Distance_Transform(lidar, src_thr=0.001, val_thr=0.1, floor=None):
     """eval_NYU.py:120-133 (src_thr=0.001 as eval_NYU.py:115; the notebooks use 0.1).
-    One frame squeezable to [H,W]; the result keeps the input's dtype like the reference."""
+    One frame squeezable to [H,W]; the result keeps the input's dtype like the reference.
+    floor=0.9 folds eval_NYU.py:205 (relu(depth - 0.9) + 0.9, float32) into the same pass."""
     src = np.asarray(lidar)
     x = np.squeeze(_as_f32_frames(src))
     if x.ndim != 2:
@@ -63,7 +67,7 @@ def Distance_Transform(lidar, src_thr=0.001, val_thr=0.1):
         # eval_NYU.py:125 squeezes the value list; with exactly one valid pixel it becomes 0-d and
         # the gather on the next line raises -- kept, so callers see the reference's behaviour
         raise IndexError("too many indices for array: array is 0-dimensional, but 1 were indexed")
-    out = _device.default_op().run_numpy(x[None], src_thr=src_thr, val_thr=val_thr, want=("depth",))
+    out = _device.default_op().run_numpy(x[None], src_thr=src_thr, val_thr=val_thr, want=("depth",), depth_floor=floor)
     depth = out["depth"][0]
     return depth.astype(src.dtype) if src.dtype.kind == "f" else depth
 

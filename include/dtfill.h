@@ -97,6 +97,20 @@ int dtfill_batch_flags(const float *x, int B, int H, int W, float src_thr, float
                        void *workspace, size_t ws_bytes, void *stream, unsigned flags);
 
 /*
+ * dtfill_batch_flags() with the drivers' post-fill steps folded into the depth stores (l1_cv only):
+ *   depth_row0  out_depth holds rows [depth_row0, H) of every frame: float32 [B, H - depth_row0, W]
+ *               (demo.py:292-293: lidar_batch = lidar_batch[:, 96:, :, :] right after DT_complete_batch)
+ *   use_floor   out_depth = relu(d - floor_) + floor_ in float32, both roundings kept
+ *               (eval_NYU.py:205, test.py:133: the 0.9 m depth floor)
+ * out_dt / out_index stay whole frames.  Saves the separate dtfill_crop_floor() pass over the filled depth.
+ * depth_row0 = 0 and use_floor = 0 is dtfill_batch_flags().  DTFILL_ERR_METRIC for the l2 metric with an epilogue.
+ */
+int dtfill_batch_epilogue(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
+                          float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
+                          void *workspace, size_t ws_bytes, void *stream, unsigned flags, int depth_row0,
+                          int use_floor, float floor_);
+
+/*
  * Same pass, instrumented for bench.py: records a HIP event on `stream` before and after every
  * kernel, synchronises, and returns each kernel's duration in milliseconds in kernel_ms (HOST
  * float[dtfill_num_kernels(metric)]; 0 for kernels the flags skip).  Not for production use (it blocks).

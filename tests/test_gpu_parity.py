@@ -648,3 +648,37 @@ def test_fill_sharded_on_the_gpu(pkg, oracle):
         rc = subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                               "--master-addr", "127.0.0.1", "--master-port", str(port), worker])
         assert rc == 0
+
+
+def test_depth_epilogue_fused_into_the_stores(gpu_op, oracle, pkg):
+    """the drivers' next lines after the fill -- rows 96: (demo.py:292-293) and the depth floor
+    relu(d - 0.9) + 0.9 (eval_NYU.py:205) -- folded into the depth stores of both kernel families and of k_tiesx;
+    bit-exact with the composed oracle calls."""
+    import torch
+
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    rng = np.random.default_rng(5)
+    xs = [synth.make("kitti_b32", B=3), synth.make("kitti_b32_scanline", B=3)]
+    a = np.zeros((2, 300, 420), np.float32)  # diagonal pairs: chains that cross tiles and the cut row (k_tiesx)
+    a[0, 250, 60] = 0.95; a[0, 246, 64] = 2.5; a[1, 20, 300] = 0.95; a[1, 24, 304] = 2.5; a[1, 150, 100] = 0.92
+    xs.append(a)
+    xs.append(np.where(rng.random((2, 97, 130)) < 0.01, rng.uniform(0.9, 3.0, (2, 97, 130)), 0).astype(np.float32))
+    for x in xs:
+        depth, dt, lbl, status = oracle.fill_batch(x)
+        assert not status.any()
+        for r0, fl in ((96, None), (0, 0.9), (96, 0.9), (17, 1.5)):
+            want = depth[:, r0:]
+            if fl is not None:
+                want = oracle.depth_floor(want, fl)
+            for path in PATHS:
+                xd = torch.from_numpy(x).to("cuda:0")
+                res = gpu_op.run(xd, path=path, depth_rows_from=r0, depth_floor=fl)
+                torch.cuda.synchronize()
+                assert tuple(res["depth"].shape) == want.shape
+                assert np.array_equal(res["depth"].cpu().numpy(), want), (x.shape, r0, fl, path)
+                assert np.array_equal(res["dt"].cpu().numpy(), dt) and np.array_equal(res["index"].cpu().numpy(), lbl)
+    # through the reference-named functions
+    batch = xs[0][:2, :, :, None]
+    assert np.array_equal(pkg.DT_complete_batch(batch, first_row=96), oracle.kitti_rows(oracle.DT_complete_batch(batch)))
+    one = xs[1][0]
+    assert np.array_equal(pkg.Distance_Transform(one, 0.1, floor=0.9), oracle.depth_floor(oracle.Distance_Transform(one, 0.1)))
