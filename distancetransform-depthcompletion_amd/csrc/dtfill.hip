@@ -46,6 +46,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/dtfill.h"
 
 typedef uint16_t u16;
@@ -236,34 +237,51 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     return ok ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
 
-constexpr int NK_L2 = 4;
-const char *const kNamesL2[NK_L2] = {"k_mask", "k_frame", "k_colT", "k_l2row"};
+constexpr int NK_L2 = 7;
+const char *const kNamesL2[NK_L2] = {"k_mask", "k_frame", "k_l2win<10>", "k_l2win<15>", "k_l2far", "k_colT", "k_l2row"};
 
 int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, float *out_depth, float *out_dt,
-           int32_t *out_index, int32_t *frame_status, void *workspace, hipStream_t st, hipEvent_t *ev) {
+           int32_t *out_index, int32_t *frame_status, void *workspace, unsigned flags, hipStream_t st, hipEvent_t *ev) {
     const Carve c = carve(workspace, B, H, W);
     const int Wd = (W + 63) / 64;
     int *status = frame_status ? frame_status : c.status;
+    const bool general_only = flags & DTFILL_FLAG_GENERAL_ONLY;
     int k = 0;
+    bool ok = true;
     auto mark = [&]() {
+        ok = ok && hipGetLastError() == hipSuccess;  // after every launch
         if (ev) (void)hipEventRecord(ev[k++], st);
     };
     mark();
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
-                               c.finfo, c.vlist, c.fflag2, c.route, status, 0);
+                               c.finfo, c.vlist, c.fflag2, c.route, status, general_only ? 1 : 0);
     mark();
+    // dense frames (k_frame's route 16 / 32): windows of 15 x 15 / 31 x 31 around every pixel, the few pixels with no source
+    // that near one by one
+    const int ttx = (W + W2_TW - 1) / W2_TW, tty = (H + W2_TH - 1) / W2_TH;
+    k_l2win<W2_R16><<<dim3(ttx * tty, B), 256, L2Win<W2_R16>::LDS, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, c.xlist,
+                                                                         c.route, 16, H, W, Wd, ttx, out_depth, out_dt, out_index, status);
+    mark();
+    k_l2win<W2_R32><<<dim3(ttx * tty, B), 256, L2Win<W2_R32>::LDS, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, c.xlist,
+                                                                         c.route, 32, H, W, Wd, ttx, out_depth, out_dt, out_index, status);
+    mark();
+    // one wave per listed pixel: enough blocks per frame for ~16 k waves in the batch
+    k_l2far<<<dim3(min(256, max(16, 4096 / B)), B), 256, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, c.xlist, c.route,
+                                                                  H, W, Wd, out_depth, out_dt, out_index, status);
+    mark();
+    // the other frames: vertical distances per column (k_colT), then the row search
     {
         const int cw = min(16, max(2, (c.nb + 1) / 2));
-        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, (size_t)c.nb * 64 * 2 * sizeof(u16), st>>>(c.srcbits, nullptr, H, W, Wd, c.nb,
+        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, (size_t)c.nb * 64 * 2 * sizeof(u16), st>>>(c.srcbits, c.fflag2, H, W, Wd, c.nb,
                                                                                            c.ctp, c.ct, nullptr, nullptr, nullptr);
     }
     mark();
     k_l2row<<<dim3(H, B), 256, (size_t)W * sizeof(u16), st>>>(x, c.ct, c.ctp, c.nb, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist,
-                                                         H, W, Wd, out_depth, out_dt, out_index, status);
+                                                         H, W, Wd, out_depth, out_dt, out_index, status, c.route);
     mark();
-    return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
+    return ok ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
 
 int check_args(const float *x, int B, int H, int W, int metric, float *out_depth, float *out_dt,
@@ -307,7 +325,7 @@ int dtfill_batch_flags(const float *x, int B, int H, int W, float src_thr, float
     int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes);
     if (rc != DTFILL_OK) return rc;
     if (metric == DTFILL_METRIC_L2)
-        return run_l2(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace,
+        return run_l2(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags,
                       static_cast<hipStream_t>(stream), nullptr);
     return run_l1(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags,
                   static_cast<hipStream_t>(stream), nullptr);
@@ -385,11 +403,12 @@ int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float
     if (!kernel_ms) return DTFILL_ERR_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nk = dtfill_num_kernels(metric);
+    static_assert(NK_L2 <= NK_L1, "event array");
     hipEvent_t ev[NK_L1 + 1];
     for (int k = 0; k <= nk; ++k)
         if (hipEventCreate(&ev[k]) != hipSuccess) return DTFILL_ERR_NO_DEVICE;
     rc = metric == DTFILL_METRIC_L2
-             ? run_l2(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, st, ev)
+             ? run_l2(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags, st, ev)
              : run_l1(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags, st,
                       ev);
     (void)hipEventSynchronize(ev[nk]);

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 n=0
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY" "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum"; do
   n=$((n+1))
-  rocprofv3 --pmc $grp --output-format csv -d $out/g$n -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --workload ${1:-kitti_b32_scanline} > $out/g$n.log 2>&1 || echo "group $n failed"
+  rocprofv3 --pmc $grp --output-format csv -d $out/g$n -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --workload ${1:-kitti_b32_scanline} --metric ${METRIC:-l1_cv} > $out/g$n.log 2>&1 || echo "group $n failed"
 done
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'

@@ -258,3 +258,39 @@ def nearest_point_argmin(x, src_thr=0.1, return_stats=False):
     if return_stats:
         return dt, label.astype(np.int32), dict(ties=len(ti), hops=hops)
     return dt, label.astype(np.int32)
+
+
+# ---- l2 mode, dense frames: the window formulation of k_l2win (dtfill_l2.hpp) --------------------------------
+
+def l2_window(src, R):
+    """Exact squared Euclidean distance and nearest source (smallest source row, then column) for every pixel that has a
+    source within distance R, from the separable form d2 = min_dy dy^2 + hx(i + dy, j)^2 over the (2R+1) rows around the
+    pixel, hx = horizontal distance to the row's nearest source, left preferred on a tie and capped at R.  The packed key
+    (d2, row, side) is the one the kernel minimises.  Returns d2, near (raster index of the source), decided (bool)."""
+    src = np.asarray(src, bool)
+    H, W = src.shape
+    jj = np.arange(W)
+    big = 1 << 20
+    # nearest source at or left / at or right of every pixel, per row
+    left = np.where(src, jj[None, :], -big)
+    left = np.maximum.accumulate(left, axis=1)
+    right = np.where(src, jj[None, :], big)
+    right = np.minimum.accumulate(right[:, ::-1], axis=1)[:, ::-1]
+    dxl, dxr = jj[None, :] - left, right - jj[None, :]
+    dx = np.minimum(dxl, dxr)
+    side = (dxr < dxl).astype(np.int64)
+    none = (R + 1) * (R + 1)
+    e = np.where(dx <= R, dx * dx, none).astype(np.int64) << 6 | np.where(dx <= R, side, 0)
+    ep = np.full((H + 2 * R, W), none << 6, np.int64)  # rows outside the frame hold nothing
+    ep[R:R + H] = e
+    best = np.full((H, W), np.iinfo(np.int64).max)
+    for dyi in range(2 * R + 1):
+        dy = dyi - R
+        best = np.minimum(best, ep[dyi:dyi + H] + ((dy * dy) << 6 | dyi << 1))
+    d2 = best >> 6
+    decided = d2 <= R * R
+    dy = ((best >> 1) & 31) - R
+    dxw = np.sqrt(np.maximum(d2 - dy * dy, 0)).round().astype(np.int64)
+    sc = np.where(best & 1, jj[None, :] + dxw, jj[None, :] - dxw)
+    sr = np.arange(H)[:, None] + dy
+    return d2, sr * W + sc, decided

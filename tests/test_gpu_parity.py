@@ -296,6 +296,73 @@ def test_l2_full_size_properties(pkg, oracle):
         assert np.allclose(np.sqrt(d2.astype(np.float32)), dt[b], rtol=1e-6)
 
 
+def assert_l2_equal_to_oracle(oracle, op2, x, st=0.1, vt=0.1, paths=("auto", "general")):
+    """l2 mode through both kernel families (window + far list for dense frames, column distances + row search for
+    the others): index bit-exact, distance sqrtf of the exact integer, depth through the value-list glue."""
+    import torch
+
+    depth, dt, idx, status = oracle.fill_batch(x, st, vt, metric="l2")
+    for path in paths:
+        res = op2.run(torch.from_numpy(x).to("cuda:0"), st, vt, path=path)
+        torch.cuda.synchronize()
+        got = {k: v.cpu().numpy() for k, v in res.items()}
+        bad = got["index"] != idx
+        assert not bad.any(), "l2 %s: index differs at %d px, first %s" % (path, bad.sum(), np.argwhere(bad)[:3].tolist())
+        assert np.allclose(got["dt"], dt, rtol=1e-6, atol=0), "l2 %s: distance differs" % path
+        assert np.array_equal(np.isinf(got["dt"]), np.isinf(dt))
+        assert np.array_equal(got["status"] & 1, status)
+        ok = status == 0
+        assert np.array_equal(got["depth"][ok], depth[ok], equal_nan=True), "l2 %s: depth differs" % path
+
+
+def test_l2_window_kernel_and_far_list(pkg, oracle):
+    """The dense-frame l2 kernels: windows of 15 x 15 (route 16) and 31 x 31 (route 32) with the far list behind them.
+    Densities either side of both routing thresholds, holes that leave thousands of pixels without a source in their
+    window, lattices (every pixel a tie), shapes that are not multiples of the tile, frames of different routes in one
+    batch, misaligned value lists."""
+    op2 = pkg.device.DtFill(device="cuda:0", metric="l2")
+    rng = np.random.default_rng(2025)
+    for (B, H, W, p) in [(2, 97, 300, 0.05), (1, 64, 256, 0.03), (2, 33, 513, 0.3), (1, 130, 1216, 0.012), (2, 75, 700, 0.008),
+                         (1, 352, 1216, 0.05), (3, 40, 65, 0.1), (1, 31, 255, 0.9), (1, 200, 257, 0.02)]:
+        x = np.where(rng.random((B, H, W)) < p, rng.uniform(0.95, 80, (B, H, W)), 0).astype(np.float32)
+        assert_l2_equal_to_oracle(oracle, op2, x)
+    # holes: a block without sources in the middle of a dense frame, touching / not touching the border
+    x = np.where(rng.random((3, 160, 600)) < 0.06, rng.uniform(0.95, 80, (3, 160, 600)), 0).astype(np.float32)
+    x[0, 40:120, 200:420] = 0
+    x[1, :, 500:] = 0
+    x[2, 100:, :90] = 0
+    assert_l2_equal_to_oracle(oracle, op2, x)
+    # lattices of period 2..9: dense enough for the window kernel, every pixel between sources is a tie
+    for per in (2, 3, 4, 6, 9):
+        lat = np.zeros((1, 70, 330), np.float32)
+        lat[0, ::per, ::per] = 5.0
+        lat[0, 3::per * 2, 1::per * 3] = 7.0
+        assert_l2_equal_to_oracle(oracle, op2, lat)
+    # one batch, three routes: 5 % (window 15), 1.2 % (window 31), 0.05 % (row search); and misaligned enumerations
+    x = np.zeros((3, 128, 640), np.float32)
+    for b, p in enumerate((0.05, 0.012, 0.0005)):
+        x[b] = np.where(rng.random((128, 640)) < p, rng.uniform(0.95, 80, (128, 640)), 0)
+    assert_l2_equal_to_oracle(oracle, op2, x)
+    x[0, 5, :40] = 0.5  # values that are not sources
+    assert_l2_equal_to_oracle(oracle, op2, x)
+    assert_l2_equal_to_oracle(oracle, op2, np.where(x > 0, rng.uniform(0.7, 10, x.shape), 0).astype(np.float32), 0.001, 0.1)
+
+
+def test_l2_sparse_shapes(pkg, oracle):
+    """l2 on the sparse configurations: NYU 480 x 640 with 20 and 200 samples, 2048 x 2048 at 1 %."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    op2 = pkg.device.DtFill(device="cuda:0", metric="l2")
+    rng = np.random.default_rng(99)
+    for n in (20, 200):
+        x = np.zeros((2, 480, 640), np.float32)
+        for b in range(2):
+            pos = rng.choice(480 * 640, n, replace=False)
+            x[b].flat[pos] = rng.uniform(0.95, 10, n)
+        assert_l2_equal_to_oracle(oracle, op2, x)
+    x = synth.make("synth2048_b16", B=1)
+    assert_l2_equal_to_oracle(oracle, op2, x)
+
+
 def test_extreme_shapes_vs_oracle(gpu_op, oracle):
     """Shapes that stress the index arithmetic: rows wider than 4096 pixels (more than 64 bit words
     per row), tall thin frames, the largest supported H+W, and a batch with many small frames."""

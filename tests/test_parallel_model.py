@@ -82,3 +82,23 @@ def test_hypothesis_arbitrary_masks(oracle):
         assert np.array_equal(dt0, dt2) and np.array_equal(l0, l2)
 
     check()
+
+
+def test_l2_window_form_matches_the_exact_transform(oracle):
+    """k_l2win's formulation (tests/parallel_model.py::l2_window): wherever a source lies within R, the packed-key minimum
+    over the window rows gives the exact squared distance and the canonical nearest source."""
+    rng = np.random.default_rng(5)
+    for t in range(30):
+        H, W = int(rng.integers(2, 60)), int(rng.integers(2, 90))
+        p = float(rng.choice([0.01, 0.05, 0.2, 0.6]))
+        src = rng.random((H, W)) < p
+        if t % 5 == 0:
+            src[:] = False
+            src[::3, ::3] = True  # lattice: ties everywhere
+        if not src.any():
+            continue
+        d2o, nearo = oracle.edt_l2((~src).astype(np.uint8))  # the mask is cv2-style: 0 = source
+        for R in (7, 15):
+            d2, near, decided = PM.l2_window(src, R)
+            assert np.array_equal(decided, d2o <= R * R)
+            assert np.array_equal(d2[decided], d2o[decided]) and np.array_equal(near[decided], nearo[decided])
