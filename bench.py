@@ -133,7 +133,7 @@ def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, w
     algo_bytes = BYTES_PER_PIXEL * B * H * W
     achieved = algo_bytes / (live[dom] * 1e-3) / 1e9
     tr = None
-    t = (traffic or {}).get(workload or "", {})
+    t = (traffic or {}).get(workload or "", {})  # keys of profiles/traffic.json: <workload> or <workload>_l2
     if t.get("batch") == B and dom in t.get("kernels", {}):
         k = t["kernels"][dom]
         tr = k["fetch_bytes"] + k["write_bytes"]
@@ -234,8 +234,9 @@ def main():
     xh = synth.make(args.workload, B=B, seed=cfg["kwargs"]["seed"] + rank)
     _, H, W = xh.shape
     x = torch.from_numpy(xh).to(dev)
+    sfx = "_l2" if args.metric == "l2" else ""
     res, roof = measure(op, torch, x, args.steps, args.warmup, args.path, barrier, reduce_max, repeats=5,
-                        workload=args.workload, traffic=traffic)
+                        workload=args.workload + sfx, traffic=traffic)
 
     sharded = None
     if world > 1 or args.sharded:
@@ -290,6 +291,18 @@ def main():
                             "frames_on_general_path": r["frames_on_general_path"]}
                 del xw
             line["workloads"] = wl
+            # the Euclidean mode (north_star's transform; the reference itself only calls the L1 one) on the same batches
+            op2 = pkg.device.DtFill(device=dev, metric="l2")
+            l2 = {}
+            for name in (args.workload,) + tuple(EXTRA_WORKLOADS):
+                c = synth.CONFIGS[name]
+                xw = x if name == args.workload else torch.from_numpy(synth.make(name)).to(dev)
+                r, rf = measure(op2, torch, xw, 30, 10, "auto", barrier, reduce_max, workload=name + "_l2", traffic=traffic)
+                l2[name] = {"value": round(xw.shape[0] * 30 / r["elapsed"], 1), "unit": "frames/s", "frames": int(xw.shape[0]),
+                            "ms_per_step": r["ms_per_step"], "roofline": rf}
+                del xw
+            line["l2"] = l2
+            del op2
             # numpy in / numpy out through the reference-named function (H2D + pass + D2H, pinned staging)
             e2e = {}
             for nb in (1, B):

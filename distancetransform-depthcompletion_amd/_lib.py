@@ -20,6 +20,7 @@ FRAME_INDEX_ERROR = 1  # bit
 FRAME_GENERAL_PATH = 2  # bit, informational
 FLAG_GENERAL_ONLY = 1
 FLAG_FUSED_ONLY = 2
+FLAG_OUTLIER_REMOVAL = 4  # outlier_removal() (data_read.py:103-128) in front of the predicates
 PATHS = {"auto": 0, "general": FLAG_GENERAL_ONLY, "fused": FLAG_FUSED_ONLY}
 
 # every symbol include/dtfill.h declares (tests/test_abi.py checks the .so exports exactly these)

@@ -83,7 +83,7 @@ struct Carve {
     float *dscratch;     // k_fin -> k_tiesx: depths of the rows a depth epilogue drops from the output
     u32 *spix;           // k_rows -> k_fin: per pixel, the frame offset of its nearest source in column kmin
     int32_t *labelmap;   // k_labels: at every source pixel, its label (1 + raster rank among the frame's sources)
-    int *finfo, *fflag2, *route, *status;
+    int *finfo, *fflag2, *route, *status, *negflag;
     float *vlist;
     size_t total;
 };
@@ -113,6 +113,7 @@ Carve carve(void *ws, int B, int H, int W) {
     c.fflag2 = (int *)take((size_t)B * 4);
     c.route = (int *)take((size_t)B * 4);
     c.status = (int *)take((size_t)B * 4);
+    c.negflag = (int *)take((size_t)B * 4);
     // any-distance path (touched only for frames the fused kernel does not take)
     c.nb = (H + 31) / 32;
     c.ctp = ct_pitch(W);
@@ -137,9 +138,16 @@ bool shape_ok(int B, int H, int W) {
 constexpr int NK_L1 = 7;
 const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_colT", "k_rows", "k_fin", "k_tiesx"};
 
-// k_mask4 when the rows can be read 16 bytes at a time, k_mask otherwise (same outputs)
-void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, float val_thr, const Carve &c, hipStream_t st) {
-    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+// k_mask4 when the rows can be read 16 bytes at a time, k_mask otherwise (same outputs); with DTFILL_FLAG_OUTLIER_REMOVAL the
+// predicates see outlier_removal(x) (k_mask_o, then its exhaustive variant for the frames that hold a negative value)
+void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, float val_thr, const Carve &c, unsigned flags,
+                 hipStream_t st) {
+    if (flags & DTFILL_FLAG_OUTLIER_REMOVAL) {
+        k_mask_o<false><<<dim3((H + 3) / 4, B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v,
+                                                              c.rowcnt_s, c.rowcnt_v, c.negflag);
+        k_mask_o<true><<<dim3((H + 3) / 4, B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v,
+                                                             c.rowcnt_s, c.rowcnt_v, c.negflag);
+    } else if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
         k_mask4<<<dim3((H + 3) / 4, B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s,
                                                       c.wpre_v, c.rowcnt_s, c.rowcnt_v);
     else
@@ -163,10 +171,10 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         if (ev) (void)hipEventRecord(ev[k++], st);
     };
     mark();
-    launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
+    launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, flags, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s,
-                               c.rowbase_v, c.finfo, c.vlist, c.fflag2, c.route, status, general_only ? 1 : 0);
+                               c.rowbase_v, c.finfo, c.vlist, c.fflag2, c.route, status, general_only ? 1 : 0, c.negflag);
     mark();
     if (!general_only) {
         // dense frames: the window kernel, halo 16 or 32 per frame (k_frame's route).  It hands a frame on (fflag2) when a
@@ -238,7 +246,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
 }
 
 constexpr int NK_L2 = 7;
-const char *const kNamesL2[NK_L2] = {"k_mask", "k_frame", "k_l2win<10>", "k_l2win<15>", "k_l2far", "k_colT", "k_l2row"};
+const char *const kNamesL2[NK_L2] = {"k_mask", "k_frame", "k_l2win<10>", "k_l2win<15>", "k_l2far", "k_colT", "k_l2env"};
 
 int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, float *out_depth, float *out_dt,
            int32_t *out_index, int32_t *frame_status, void *workspace, unsigned flags, hipStream_t st, hipEvent_t *ev) {
@@ -253,10 +261,10 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         if (ev) (void)hipEventRecord(ev[k++], st);
     };
     mark();
-    launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, st);
+    launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, flags, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
-                               c.finfo, c.vlist, c.fflag2, c.route, status, general_only ? 1 : 0);
+                               c.finfo, c.vlist, c.fflag2, c.route, status, general_only ? 1 : 0, c.negflag);
     mark();
     // dense frames (k_frame's route 16 / 32): windows of 15 x 15 / 31 x 31 around every pixel, the few pixels with no source
     // that near one by one
@@ -271,23 +279,32 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     k_l2far<<<dim3(min(256, max(16, 4096 / B)), B), 256, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, c.xlist, c.route,
                                                                   H, W, Wd, out_depth, out_dt, out_index, status);
     mark();
-    // the other frames: vertical distances per column (k_colT), then the row search
+    // the other frames: vertical distances per column (k_colT), then the lower envelope of every row
     {
         const int cw = min(16, max(2, (c.nb + 1) / 2));
         k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, (size_t)c.nb * 64 * 2 * sizeof(u16), st>>>(c.srcbits, c.fflag2, H, W, Wd, c.nb,
                                                                                            c.ctp, c.ct, nullptr, nullptr, nullptr);
     }
     mark();
-    k_l2row<<<dim3(H, B), 256, (size_t)W * sizeof(u16), st>>>(x, c.ct, c.ctp, c.nb, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist,
-                                                         H, W, Wd, out_depth, out_dt, out_index, status, c.route);
+    {
+        const size_t lds = (size_t)W * 10;
+        static bool big_lds_set = false;
+        if (lds > 48 * 1024 && !big_lds_set) {  // rows wider than ~4900 pixels
+            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_l2env), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 10) == hipSuccess;
+            big_lds_set = true;
+        }
+        k_l2env<<<dim3(H, B), 256, lds, st>>>(x, c.ct, c.ctp, c.nb, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd,
+                                             out_depth, out_dt, out_index, status, c.route);
+    }
     mark();
     return ok ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
 
 int check_args(const float *x, int B, int H, int W, int metric, float *out_depth, float *out_dt,
-               int32_t *out_index, void *workspace, size_t ws_bytes) {
+               int32_t *out_index, void *workspace, size_t ws_bytes, unsigned flags = 0u) {
     if (!x || !workspace || (!out_depth && !out_dt && !out_index)) return DTFILL_ERR_NULL;
     if (!shape_ok(B, H, W)) return DTFILL_ERR_SHAPE;
+    if ((flags & DTFILL_FLAG_OUTLIER_REMOVAL) && (H < 4 || W < 4)) return DTFILL_ERR_SHAPE;  // the 7x7 filter's reflected border
     if (metric != DTFILL_METRIC_L1_CV && metric != DTFILL_METRIC_L2) return DTFILL_ERR_METRIC;
     if (ws_bytes < dtfill_workspace_bytes(B, H, W, metric) || ((uintptr_t)workspace & 255))
         return DTFILL_ERR_WORKSPACE;
@@ -322,7 +339,7 @@ size_t dtfill_workspace_bytes(int B, int H, int W, int metric) {
 int dtfill_batch_flags(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
                        float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
                        void *workspace, size_t ws_bytes, void *stream, unsigned flags) {
-    int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes);
+    int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes, flags);
     if (rc != DTFILL_OK) return rc;
     if (metric == DTFILL_METRIC_L2)
         return run_l2(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags,
@@ -342,7 +359,7 @@ int dtfill_batch_epilogue(const float *x, int B, int H, int W, float src_thr, fl
                           float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
                           void *workspace, size_t ws_bytes, void *stream, unsigned flags, int depth_row0, int use_floor,
                           float floor_) {
-    int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes);
+    int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes, flags);
     if (rc != DTFILL_OK) return rc;
     if (depth_row0 < 0 || depth_row0 >= H) return DTFILL_ERR_SHAPE;
     if (metric != DTFILL_METRIC_L1_CV) return (depth_row0 || use_floor) ? DTFILL_ERR_METRIC : dtfill_batch_flags(x, B, H, W, src_thr, val_thr, metric, out_depth, out_dt, out_index, frame_status, workspace, ws_bytes, stream, flags);
@@ -398,7 +415,7 @@ const char *dtfill_kernel_name(int metric, int k) {
 int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
                        float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
                        void *workspace, size_t ws_bytes, void *stream, unsigned flags, float *kernel_ms) {
-    int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes);
+    int rc = check_args(x, B, H, W, metric, out_depth, out_dt, out_index, workspace, ws_bytes, flags);
     if (rc != DTFILL_OK) return rc;
     if (!kernel_ms) return DTFILL_ERR_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);

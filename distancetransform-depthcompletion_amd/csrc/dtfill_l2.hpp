@@ -299,90 +299,153 @@ __global__ __launch_bounds__(256) void k_l2far(const float *__restrict__ x, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// l2 metric: k_l2row.  One lane per pixel.  With g(i,k) the vertical distance to the nearest source of
-// column k (from k_colT's band words), the exact squared Euclidean distance is min_k g(i,k)^2 + (j-k)^2; the columns are visited
-// outward from j (r = |j-k| = 0,1,2,...) and the search stops once r^2 exceeds the best value, so the
-// work per pixel is ~2 sqrt(d^2) candidates.  Ties go to the smallest raster index of the SOURCE
-// (smaller row, then smaller column) -- the order brute force gives.  Then rank -> label, gather, store.
+// l2 metric, every other frame: k_l2env -- the row pass of the two-pass Euclidean transform (Felzenszwalb / Meijster) as a
+// search over the lower envelope of parabolas.  With g(k) the vertical distance from row i to the nearest source of column
+// k (k_colT's band words), pixel j takes min_k g(k)^2 + (j-k)^2: the lowest of the parabolas rooted at the columns.  Two
+// parabolas of the same curvature cross once, so the column that owns pixel j never moves left as j moves right, whatever
+// rule breaks the ties.  That monotonicity replaces the sequential stack: solve j = 0 and j = W-1 over all columns, then
+// the midpoints level by level -- the owner of a midpoint lies between the owners of its solved neighbours -- so a level
+// looks at every column about once: O(W log W) per row, any distance, no data-dependent radius.
+//   * one block per row; the columns that hold a source are compacted into LDS as {g^2, source row << 16 | column};
+//   * a level's queries are shared out over the block: 256 / queries lanes per query (candidates strided over the lanes,
+//     minimum by wave shuffles), one lane per query once there are 256 or more;
+//   * keys compare as (d2, source row, column): ties go to the smallest raster index of the source, as brute force does.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_l2row(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
+struct L2Cand {
+    u32 hi, lo, idx;  // squared distance, source row << 16 | column, position in the compacted column list
+};
+__device__ __forceinline__ void l2env_offer(L2Cand &best, const uint2 *__restrict__ s_c, int cc, int j) {
+    const uint2 cv = s_c[cc];
+    const int dk = j - (int)(cv.y & 0xFFFFu);
+    const u32 hi = cv.x + (u32)(dk * dk);
+    if (hi < best.hi || (hi == best.hi && cv.y < best.lo)) {
+        best.hi = hi;
+        best.lo = cv.y;
+        best.idx = (u32)cc;
+    }
+}
+__device__ __forceinline__ void l2env_merge(L2Cand &best, int off) {
+    const u32 oh = (u32)__shfl_xor((int)best.hi, off), ol = (u32)__shfl_xor((int)best.lo, off), oi = (u32)__shfl_xor((int)best.idx, off);
+    if (oh < best.hi || (oh == best.hi && ol < best.lo)) {
+        best.hi = oh;
+        best.lo = ol;
+        best.idx = oi;
+    }
+}
+
+constexpr u32 L2_NOSRC = 0x3FFFFFFFu;  // g^2 of a column without a source
+__global__ __launch_bounds__(256) void k_l2env(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
                                                const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
                                                const u32 *__restrict__ rowbase_s, const int *__restrict__ finfo,
                                                const float *__restrict__ vlist, int H, int W, int Wd,
                                                float *__restrict__ out_depth, float *__restrict__ out_dt,
                                                int32_t *__restrict__ out_index, int *__restrict__ frame_status,
                                                const int *__restrict__ route) {
-    // one block per image row: the row of g is staged in LDS once, every pixel's outward search reads it there
-    extern __shared__ __attribute__((aligned(16))) u16 s_grow[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_env[];
+    __shared__ u32 s_wcnt[4];
+    __shared__ u32 s_red[4][3];
     const int b = blockIdx.y, i = blockIdx.x;
     if (route[b] != 0) return;  // k_l2win + k_l2far took the frame
+    uint2 *s_c = reinterpret_cast<uint2 *>(s_env);               // [W] the columns with a source, in column order
+    u16 *s_own = reinterpret_cast<u16 *>(s_env + (size_t)W * 8);  // [W] owner of every solved pixel (index into s_c)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t fo = (size_t)b * H * W;
+    // columns -> {g^2, source row << 16 | column}, compacted
+    int c = 0;
     {
-        // vertical distance to the nearest source of every column, from k_colT's band words (as in k_rows); bit 15:
-        // that source is BELOW this row (strictly nearer than the one above: on a vertical tie the upper source has the
-        // smaller raster index)
         const int band = i >> 5, r = i & 31;
         const uint2 *crow = ct + ((size_t)b * nb + band) * CTP;
         const u32 upmask = (2u << r) - 1u;
-        for (int k = threadIdx.x; k < W; k += 256) {
-            const uint2 c = crow[k];
-            const u32 gu = min(ffbh_u32(c.x & upmask) + (u32)(r - 31), (c.y & 0xFFFFu) + (u32)r);
-            const u32 gd = min(ffbl_b32(c.x >> r), (c.y >> 16) + (u32)(31 - r));
-            const u32 m = min(gu, gd);
-            s_grow[k] = m >= (u32)MAX_HW_SUM ? (u16)INF16 : (u16)(m | (gd < gu ? 0x8000u : 0u));  // >= 8192: no source in the column
-        }
-    }
-    __syncthreads();
-    const u16 *grow = s_grow;
-    for (int j = threadIdx.x; j < W; j += 256) {
-    const int p = i * W + j;
-    // best candidate: key = (d2, source row, source column), lexicographic
-    long long best = 0x7FFFFFFFFFFFFFFFll;
-    int bestd2 = 0x7FFFFFFF;
-    const int rmax = finfo[b * FI_STRIDE + FI_NSRC] ? W : 0;  // a frame without sources has nothing to search
-    constexpr int RC = 4;  // radii per chunk: their 2*RC loads are issued together, then applied in order
-    for (int r0 = 0; r0 < rmax; r0 += RC) {
-        if ((long long)r0 * r0 > bestd2) break;  // r*r == bestd2 still matters: a same-row source ties on d2
-        int v[RC][2];
-#pragma unroll
-        for (int u = 0; u < RC; ++u) {
-            const int kl = j - (r0 + u), kr = j + (r0 + u);
-            v[u][0] = kl >= 0 ? (int)grow[kl] : INF16;
-            v[u][1] = (kr < W && r0 + u > 0) ? (int)grow[kr] : INF16;
-        }
-#pragma unroll
-        for (int u = 0; u < RC; ++u) {
-            const int r = r0 + u;
-            if ((long long)r * r > bestd2) break;
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const int vv = v[u][side];
-                if (vv == INF16) continue;
-                const int k = side ? j + r : j - r;
-                const int gv = vv & 0x7FFF;
-                const int srow = (vv & 0x8000) ? i + gv : i - gv;
-                const int d2 = gv * gv + r * r;
-                const long long key = ((long long)d2 << 32) | ((long long)srow << 16) | k;
-                if (key < best) {
-                    best = key;
-                    bestd2 = d2;
-                }
+        for (int k0 = 0; k0 < W; k0 += 256) {
+            const int k = k0 + tid;
+            bool has = false;
+            uint2 cv = make_uint2(0u, 0u);
+            if (k < W) {
+                const uint2 w = crow[k];
+                const u32 gu = min(ffbh_u32(w.x & upmask) + (u32)(r - 31), (w.y & 0xFFFFu) + (u32)r);
+                const u32 gd = min(ffbl_b32(w.x >> r), (w.y >> 16) + (u32)(31 - r));
+                const u32 m = min(gu, gd);  // on a vertical tie the upper source (the smaller raster index)
+                has = m < (u32)MAX_HW_SUM;
+                cv = make_uint2(m * m, (u32)(gd < gu ? i + (int)m : i - (int)m) << 16 | (u32)k);
             }
+            const u64 bal = __ballot(has);
+            if (lane == 0) s_wcnt[wv] = (u32)__popcll(bal);
+            __syncthreads();
+            int off = c;
+            for (int w = 0; w < wv; ++w) off += (int)s_wcnt[w];
+            if (has) s_c[off + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = cv;
+            c += (int)(s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
+            __syncthreads();
         }
     }
-    int label = 0, q = p;
-    float dist = INFINITY;
-    if (bestd2 != 0x7FFFFFFF) {
-        const int srow = (int)((best >> 16) & 0xFFFF), scol = (int)(best & 0xFFFF);
-        q = srow * W + scol;
-        const size_t w = ((size_t)b * H + srow) * Wd + (scol >> 6);
-        label = source_rank(rowbase_s[(size_t)b * H + srow] + wpre_s[w], srcbits[w], scol);
-        dist = sqrtf((float)bestd2);
+    if (c > 0) {
+        // a query for the whole block: candidates strided over the 256 threads, wave shuffles, then the four wave minima
+        auto block_query = [&](int j, int lo, int hi) {
+            L2Cand best = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+            for (int cc = lo + tid; cc <= hi; cc += 256) l2env_offer(best, s_c, cc, j);
+#pragma unroll
+            for (int o = 32; o; o >>= 1) l2env_merge(best, o);
+            if (lane == 0) {
+                s_red[wv][0] = best.hi;
+                s_red[wv][1] = best.lo;
+                s_red[wv][2] = best.idx;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int w0 = 0;
+                for (int w = 1; w < 4; ++w)
+                    if (s_red[w][0] < s_red[w0][0] || (s_red[w][0] == s_red[w0][0] && s_red[w][1] < s_red[w0][1])) w0 = w;
+                s_own[j] = (u16)s_red[w0][2];
+            }
+            __syncthreads();
+        };
+        block_query(0, 0, c - 1);
+        if (W > 1) block_query(W - 1, 0, c - 1);
+        int s = 1;
+        while (s < W - 1) s <<= 1;  // s >= W - 1: the first stride below it has its odd multiples inside (0, W-1)
+        for (s >>= 1; s >= 1; s >>= 1) {
+            const int nq = W - 2 >= s ? ((W - 2) / s + 1) / 2 : 0;  // odd multiples of s in [s, W-2]
+            if (nq <= 2) {
+                for (int m = 0; m < nq; ++m) {
+                    const int j = (2 * m + 1) * s;
+                    block_query(j, (int)s_own[j - s], (int)s_own[min(j + s, W - 1)]);
+                }
+                continue;
+            }
+            int G = 64;  // lanes per query: 256 / (nq rounded up to a power of two), at most a wave, at least one
+            while (G > 1 && G * nq > 256) G >>= 1;
+            const int per = 256 / G, gl = tid & (G - 1);
+            for (int m0 = 0; m0 < nq; m0 += per) {
+                const int m = m0 + tid / G;
+                const bool act = m < nq;
+                const int j = (2 * m + 1) * s;
+                L2Cand best = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+                if (act) {
+                    const int lo = (int)s_own[j - s], hi = (int)s_own[min(j + s, W - 1)];
+                    for (int cc = lo + gl; cc <= hi; cc += G) l2env_offer(best, s_c, cc, j);
+                }
+                for (int o = G >> 1; o; o >>= 1) l2env_merge(best, o);
+                if (act && gl == 0) s_own[j] = (u16)best.idx;
+            }
+            __syncthreads();
+        }
     }
-    if (out_index) out_index[fo + p] = label;
-    if (out_dt) out_dt[fo + p] = dist;
-    if (out_depth)
-        out_depth[fo + p] = gather_depth(x + fo, vlist + fo, label, q, finfo[b * FI_STRIDE + FI_NVAL],
-                                         finfo[b * FI_STRIDE + FI_MISALIGNED], frame_status + b);
+    const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
+    for (int j = tid; j < W; j += 256) {
+        const int p = i * W + j;
+        int label = 0, q = p;
+        float dist = INFINITY;
+        if (c > 0) {
+            const uint2 cv = s_c[s_own[j]];
+            const int srow = (int)(cv.y >> 16), scol = (int)(cv.y & 0xFFFFu);
+            q = srow * W + scol;
+            const size_t w = ((size_t)b * H + srow) * Wd + (scol >> 6);
+            label = source_rank(rowbase_s[(size_t)b * H + srow] + wpre_s[w], srcbits[w], scol);
+            dist = sqrtf((float)(cv.x + (u32)((j - scol) * (j - scol))));
+        }
+        if (out_index) out_index[fo + p] = label;
+        if (out_dt) out_dt[fo + p] = dist;
+        if (out_depth) out_depth[fo + p] = gather_depth(x + fo, vlist + fo, label, q, nval, misaligned, frame_status + b);
     }
 }
+

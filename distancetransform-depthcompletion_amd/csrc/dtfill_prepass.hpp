@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
                                                u32 *__restrict__ rowbase_s, u32 *__restrict__ rowbase_v,
                                                int *__restrict__ finfo, float *__restrict__ vlist,
                                                int *__restrict__ fflag2,
-                                               int *__restrict__ route, int *__restrict__ frame_status, int mode) {
+                                               int *__restrict__ route, int *__restrict__ frame_status, int mode, int *__restrict__ negflag) {
     const bool force_general = mode & 1;  // every frame takes the any-distance kernels (tests)
     __shared__ u32 s_ws[4], s_wv[4];
     __shared__ int s_mis, s_dlb;
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         auto fits = [&](int R) { return (long long)run_s * (2 * R * R + 2 * R + 1) >= 14ll * H * W && s_dlb <= R; };
         const int r = force_general ? 0 : fits(16) ? 16 : fits(32) ? 32 : 0;
         route[b] = r;
+        negflag[b] = 0;  // k_mask_o's "this frame holds a negative value": consumed before this kernel, reset for the next pass
         const bool general = r == 0;
         fflag2[b] = general ? 1 : 0;  // also set by k_fused when it meets a pixel farther than its halo
         frame_status[b] = general ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;

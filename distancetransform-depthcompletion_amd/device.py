@@ -63,14 +63,17 @@ class DtFill:
         return int(self.lib.dtfill_workspace_bytes(B, H, W, self.metric))
 
     # -- the op --------------------------------------------------------------------------------
-    def run(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL, timed=False, path="auto", depth_rows_from=0, depth_floor=None):
+    def run(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL, timed=False, path="auto", depth_rows_from=0, depth_floor=None,
+            outlier_removal=False):
         """x: float32 CUDA tensor [B,H,W] (contiguous).  Returns a dict of device tensors
         (views of buffers owned by this object, overwritten by the next call) for the names in
         `want`, plus "status" (int32 [B], bit set of _lib.FRAME_*).  Asynchronous on the current
         stream unless timed.  path: "auto" (window kernel for dense frames, any-distance kernels for the
         others), "general" or "fused" (tests / benchmarks).  depth_rows_from / depth_floor: the drivers'
         post-fill steps folded into the depth stores (demo.py:292-293 rows 96:, eval_NYU.py:205
-        relu(d - 0.9) + 0.9): "depth" is then [B, H - depth_rows_from, W]; l1_cv only."""
+        relu(d - 0.9) + 0.9): "depth" is then [B, H - depth_rows_from, W]; l1_cv only.  outlier_removal: the loader's filter
+        (data_read.py:103-128, 168-169) in front of the predicates -- the pass equals run(outlier_removal_device(x)) without
+        the filtered map being written."""
         if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 3 or not x.is_contiguous():
             raise ValueError("x must be a contiguous float32 CUDA tensor [B,H,W]")
         B, H, W = x.shape
@@ -93,7 +96,7 @@ class DtFill:
                 ptr("depth"), ptr("dt"), ptr("index"), o["status"].data_ptr(),
                 self._ws.data_ptr() + self._ws_off, self._ws_bytes, stream,
             ]
-            flags = _lib.PATHS[path]
+            flags = _lib.PATHS[path] | (_lib.FLAG_OUTLIER_REMOVAL if outlier_removal else 0)
             if timed:
                 nk = self.lib.dtfill_num_kernels(self.metric)
                 ms = (ctypes.c_float * nk)()
@@ -109,7 +112,7 @@ class DtFill:
         res["status"] = o["status"]
         return res
 
-    def run_numpy(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL, depth_rows_from=0, depth_floor=None):
+    def run_numpy(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL, depth_rows_from=0, depth_floor=None, outlier_removal=False):
         """numpy in / numpy out: H2D, run, D2H.  x: float32 [B,H,W].  Raises IndexError exactly
         where numpy would in depth_list[label_list-1] (tools.py:26) when depth is wanted.
         The transfers go through pinned staging buffers kept per shape (the returned arrays are fresh
@@ -132,7 +135,8 @@ class DtFill:
         np.copyto(self._pin_in.numpy(), xh, casting="same_kind")  # one pass: gathers strided input, casts if needed
         with torch.cuda.device(self.device):
             self._dev_in.copy_(self._pin_in, non_blocking=True)
-            res = self.run(self._dev_in, src_thr, val_thr, want, depth_rows_from=depth_rows_from, depth_floor=depth_floor)
+            res = self.run(self._dev_in, src_thr, val_thr, want, depth_rows_from=depth_rows_from, depth_floor=depth_floor,
+                           outlier_removal=outlier_removal)
             for k, v in res.items():
                 self._pin_out[k][:, : v.shape[1]].copy_(v, non_blocking=True) if v.dim() == 3 else self._pin_out[k].copy_(v, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()

@@ -41,17 +41,19 @@ def nearest_point(refined_lidar, src_thr=0.1):
     return out["dt"][0], out["index"][0]
 
 
-def DT_complete_batch(lidar_batch, src_thr=0.1, val_thr=0.1, first_row=0, floor=None):
+def DT_complete_batch(lidar_batch, src_thr=0.1, val_thr=0.1, first_row=0, floor=None, if_removal=False):
     """tools.py:13-35.  lidar_batch [B,H,W,C>=1] (channel 0 is used, tools.py:18) ->
     float32 [B,H,W,1].  Raises IndexError like tools.py:26 when a frame's value list is too short.
     first_row / floor fold the caller's next lines into the same pass: demo.py:292-293
-    (lidar_batch[:, 96:, :, :] -> first_row=96, result [B,H-96,W,1]) and the depth floor relu(d - 0.9) + 0.9."""
+    (lidar_batch[:, 96:, :, :] -> first_row=96, result [B,H-96,W,1]) and the depth floor relu(d - 0.9) + 0.9.
+    if_removal folds the loader's outlier_removal() (data_read.py:103-128, the flag of data_read.py:168) into the same pass:
+    DT_complete_batch(x, if_removal=True) == DT_complete_batch(outlier_removal(x_i) for every frame)."""
     lb = _as_f32_frames(lidar_batch)
     if lb.ndim != 4:
         raise IndexError("too many indices for array: DT_complete_batch indexes lidar_batch[i,:,:,0]")
     x = lb[:, :, :, 0]
     out = _device.default_op().run_numpy(x, src_thr=src_thr, val_thr=val_thr, want=("depth",), depth_rows_from=first_row,
-                                         depth_floor=floor)
+                                         depth_floor=floor, outlier_removal=if_removal)
     return np.expand_dims(out["depth"], axis=-1)  # already a fresh float32 array
 
 

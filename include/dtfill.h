@@ -63,6 +63,11 @@ extern "C" {
 #define DTFILL_FLAG_GENERAL_ONLY 1u /* skip the window kernel, every frame takes the any-distance kernels */
 #define DTFILL_FLAG_FUSED_ONLY   2u /* skip the any-distance kernels: frames that need them are left
                                        undefined and carry DTFILL_FRAME_GENERAL_PATH in their status */
+/* ... and one that changes the result: the loader's outlier_removal() (data_read.py:103-128, applied to the sparse map
+   before anything else sees it, data_read.py:168-169) in front of the predicates.  The pass then equals
+   dtfill_outlier_removal() followed by dtfill_batch() on its output, without the filtered map ever being written:
+   a removed pixel stops being a source / value, the surviving ones are gathered from x.  Needs H, W >= 4. */
+#define DTFILL_FLAG_OUTLIER_REMOVAL 4u
 
 int dtfill_abi_version(void);
 const char *dtfill_strerror(int code);

@@ -21,8 +21,8 @@ def rows(pattern):
 
 
 def short(n):
-    m = re.search(r"(k_[a-zA-Z0-9_]+)(<[^>]*>)?", n)
-    return m.group(1) if m else None
+    m = re.search(r"(k_[a-zA-Z0-9_]+)(<\d+>)?", n)  # k_l2win<10> keeps its radius, k_rows<8, 256> is k_rows
+    return (m.group(1) + (m.group(2) or "")) if m else None
 
 
 print("== %s: rocprofv3 --kernel-trace --stats (mean duration per launch, us) ==" % wl)
@@ -31,7 +31,7 @@ for r in rows("trace/**/*kernel_stats.csv"):
     k = short(r["Name"])
     if k:
         dur[k] = float(r["AverageNs"]) / 1e3
-        print("%-10s calls %4s  mean %9.2f us  min %9.2f  max %9.2f" % (k, r["Calls"], dur[k], float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+        print("%-12s calls %4s  mean %9.2f us  min %9.2f  max %9.2f" % (k, r["Calls"], dur[k], float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 traffic = {"kernels": {}}
 for name, pat, scale, note, key in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv", 2.0, "x1024 B x2 (gfx950 half-count correction)", "fetch_bytes"),
                                     ("WRITE_SIZE", "pmc_write/**/*counter_collection.csv", 1.0, "x1024 B", "write_bytes")):
@@ -44,7 +44,7 @@ for name, pat, scale, note, key in (("FETCH_SIZE", "pmc_fetch/**/*counter_collec
     print("== %s per launch (%s) ==" % (name, note))
     for k, v in sorted(acc.items()):
         m = sum(v) / len(v)
-        print("%-10s launches %4d  raw %12.1f  -> %8.2f MB" % (k, len(v), m, m * 1024 * scale / 1e6))
+        print("%-12s launches %4d  raw %12.1f  -> %8.2f MB" % (k, len(v), m, m * 1024 * scale / 1e6))
         traffic["kernels"].setdefault(k, {})[key] = round(m * 1024 * scale)
 tot = sum(v.get("fetch_bytes", 0) + v.get("write_bytes", 0) for v in traffic["kernels"].values())
 print("== pass: %.1f us of kernels, %.1f MB of HBM traffic ==" % (sum(dur.values()), tot / 1e6))

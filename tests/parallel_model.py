@@ -294,3 +294,53 @@ def l2_window(src, R):
     sc = np.where(best & 1, jj[None, :] + dxw, jj[None, :] - dxw)
     sr = np.arange(H)[:, None] + dy
     return d2, sr * W + sc, decided
+
+
+# ---- l2 mode, any distance: the lower-envelope search of k_l2env (dtfill_l2.hpp) -----------------------------
+
+def l2_envelope(src):
+    """Exact squared Euclidean distance and nearest source (smallest source row, then column) by the two-pass scheme:
+    vertical distance g per column (upper source on a tie), then per row the owner of every pixel among the parabolas
+    g(k)^2 + (j-k)^2 -- found level by level: pixel 0 and W-1 over all columns, then midpoints, each between the owners of
+    its solved neighbours (the owner never moves left as j moves right).  Returns d2, near, evaluations per pixel."""
+    src = np.asarray(src, bool)
+    H, W = src.shape
+    big = 1 << 20
+    ii = np.arange(H)[:, None]
+    up = np.maximum.accumulate(np.where(src, ii, -big), axis=0)
+    dn = np.minimum.accumulate(np.where(src, ii, big)[::-1], axis=0)[::-1]
+    gu, gd = ii - up, dn - ii
+    g = np.minimum(gu, gd)
+    srow = np.where(gd < gu, dn, up)
+    d2 = np.zeros((H, W), np.int64)
+    near = np.zeros((H, W), np.int64)
+    evals = 0
+    for i in range(H):
+        cols = np.nonzero(g[i] < big // 2)[0]
+        cand = [(int(g[i, k]) ** 2, int(srow[i, k]), int(k)) for k in cols]
+        own = {}
+
+        def query(j, lo, hi):
+            nonlocal evals
+            evals += hi - lo + 1
+            best = min(range(lo, hi + 1), key=lambda c: (cand[c][0] + (j - cand[c][2]) ** 2, cand[c][1], cand[c][2]))
+            own[j] = best
+
+        query(0, 0, len(cand) - 1)
+        if W > 1:
+            query(W - 1, 0, len(cand) - 1)
+        s = 1
+        while s < W - 1:
+            s <<= 1
+        s >>= 1
+        while s >= 1:
+            nq = ((W - 2) // s + 1) // 2 if W - 2 >= s else 0
+            for m in range(nq):
+                j = (2 * m + 1) * s
+                query(j, own[j - s], own[min(j + s, W - 1)])
+            s >>= 1
+        for j in range(W):
+            g2, sr, k = cand[own[j]]
+            d2[i, j] = g2 + (j - k) ** 2
+            near[i, j] = sr * W + k
+    return d2, near, evals / (H * W)

@@ -418,6 +418,67 @@ def test_outlier_removal_vs_oracle(pkg, oracle):
         assert (want != x).any() or H < 8
 
 
+def test_outlier_removal_special_values(pkg, oracle):
+    """The kernel only gathers the 25 taps for pixels that can be removed (v > 1.0) unless a negative value is around:
+    negative values, values in (0, 1], NaN and inf must give the composed numpy answer all the same."""
+    rng = np.random.default_rng(13)
+    H, W = 90, 200
+    base = np.where(rng.random((H, W)) < 0.2, np.round(rng.uniform(0.2, 60, (H, W)) * 64) / 64, 0).astype(np.float32)
+    cases = {"plain": base.copy()}
+    neg = base.copy()
+    neg[rng.integers(0, H, 30), rng.integers(0, W, 30)] = -np.round(rng.uniform(1, 50, 30) * 8).astype(np.float32) / 8
+    cases["negative"] = neg  # a negative neighbourhood mean removes pixels with v <= 1.0 too
+    small = base.copy()
+    small[small > 0] = np.minimum(small[small > 0], 1.0)
+    small[10, 10] = -40.0
+    cases["small values next to a negative"] = small
+    nan = base.copy()
+    nan[5, 7] = np.nan
+    nan[50, 100] = np.inf
+    cases["nan / inf"] = nan
+    for name, x in cases.items():
+        got = pkg.outlier_removal(x[None, :, :, None])
+        want = oracle.outlier_removal(x)
+        assert np.array_equal(got, want, equal_nan=True), name
+    assert (cases["small values next to a negative"] != oracle.outlier_removal(cases["small values next to a negative"])).any()
+
+
+def test_outlier_removal_fused_into_the_predicates(pkg, gpu_op, oracle):
+    """SURVEY 8f-2 / data_read.py:168-169: DTFILL_FLAG_OUTLIER_REMOVAL = outlier_removal() then the fill, without the
+    filtered map.  Bit-exact with the composed oracle calls: both kernel families, both metrics, odd widths, frames with
+    negative values (the exhaustive second launch) next to frames without, misaligned value lists, the shim."""
+    import torch
+
+    rng = np.random.default_rng(14)
+    op2 = pkg.device.DtFill(device="cuda:0", metric="l2")
+    for (B, H, W, p) in [(2, 352, 1216, 0.05), (3, 61, 131, 0.1), (2, 40, 2300, 0.02), (1, 4, 4, 0.5), (2, 100, 257, 0.004)]:
+        x = np.where(rng.random((B, H, W)) < p, np.round(rng.uniform(0.95, 80, (B, H, W)) * 64) / 64, 0).astype(np.float32)
+        n = max(1, int(0.002 * H * W))
+        for b in range(B):
+            x[b, rng.integers(0, H, n), rng.integers(0, W, n)] = 79.0  # far points in front of near neighbourhoods
+        if B > 1:
+            x[1, rng.integers(0, H), rng.integers(0, W)] = -30.0       # frame 1 takes the exhaustive launch
+        xf = np.stack([oracle.outlier_removal(f) for f in x])
+        assert (xf != x).any() or H < 8
+        for metric, op in (("l1_cv", gpu_op), ("l2", op2)):
+            depth, dt, idx, status = oracle.fill_batch(xf, metric=metric)
+            for path in ("auto", "general"):
+                res = op.run(torch.from_numpy(x).to("cuda:0"), path=path, outlier_removal=True)
+                torch.cuda.synchronize()
+                got = {k: v.cpu().numpy() for k, v in res.items()}
+                assert np.array_equal(got["index"], idx), (metric, path, B, H, W)
+                assert np.allclose(got["dt"], dt, rtol=1e-6, atol=0) if metric == "l2" else np.array_equal(got["dt"], dt)
+                ok = status == 0
+                assert np.array_equal(got["status"] & 1, status) and np.array_equal(got["depth"][ok], depth[ok], equal_nan=True)
+    # values that are not sources (misaligned enumerations) + the reference-named entry point
+    x = np.where(rng.random((2, 70, 300)) < 0.1, np.round(rng.uniform(0.2, 40, (2, 70, 300)) * 64) / 64, 0).astype(np.float32)
+    xf = np.stack([oracle.outlier_removal(f) for f in x])
+    want = oracle.fill_batch(xf)[0]
+    got = pkg.DT_complete_batch(x[..., None], if_removal=True)
+    assert np.array_equal(got[..., 0], want)
+    assert np.array_equal(got, pkg.DT_complete_batch(np.stack([pkg.outlier_removal(f[None, :, :, None]) for f in x])[..., None]))
+
+
 def test_concurrent_streams_and_threads(pkg, oracle):
     """include/dtfill.h: no global state, every call ordered on its stream only.  Four operators (own
     workspaces) driven from four host threads on four streams at once, several rounds, different inputs."""

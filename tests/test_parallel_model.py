@@ -102,3 +102,25 @@ def test_l2_window_form_matches_the_exact_transform(oracle):
             d2, near, decided = PM.l2_window(src, R)
             assert np.array_equal(decided, d2o <= R * R)
             assert np.array_equal(d2[decided], d2o[decided]) and np.array_equal(near[decided], nearo[decided])
+
+
+def test_l2_envelope_search_matches_the_exact_transform(oracle):
+    """k_l2env's formulation (tests/parallel_model.py::l2_envelope): the level-by-level owner search over the lower envelope
+    gives the exact squared distance and the canonical nearest source, at ~log2(W) column evaluations per pixel."""
+    rng = np.random.default_rng(6)
+    for t in range(24):
+        H, W = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        p = float(rng.choice([0.004, 0.02, 0.1, 0.5]))
+        src = rng.random((H, W)) < p
+        if t % 6 == 0:
+            src[:] = False
+            src[::4, ::5] = True  # lattice: ties everywhere
+        if t % 6 == 1:
+            src[:] = False
+            src[rng.integers(0, H), rng.integers(0, W)] = True  # a single source
+        if not src.any():
+            continue
+        d2o, nearo = oracle.edt_l2((~src).astype(np.uint8))
+        d2, near, evals = PM.l2_envelope(src)
+        assert np.array_equal(d2, d2o) and np.array_equal(near, nearo)
+        assert evals <= 2 * np.log2(max(W, 2)) + 4
