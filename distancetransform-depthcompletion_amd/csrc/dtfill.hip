@@ -38,7 +38,11 @@
 //   k_fin      per tile: 5x5 parent rule bit-sliced for the remaining "tie" pixels, their chains (pointer
 //              doubling in LDS), label + depth of every pixel
 //   k_tiesx    the few tie pixels whose chain crosses tiles
-// l2 pass (exact Euclidean, canonical tie-break): k_mask, k_frame, k_colT, k_l2row.
+// l2 pass (exact Euclidean, canonical tie-break; dtfill_l2.hpp): k_mask, k_frame, then
+//   k_l2win<R> dense frames: (2R+1)^2 windows straight from the bit words, packed-key minimum over the window rows
+//   k_l2far    the odd far pixel of a dense frame, one wave each
+//   k_colT     vertical distances per column, for sparse frames and for rows of far pixels (the empty sky)
+//   k_l2env    those rows: lower envelope of parabolas searched by monotone bisection
 //
 // No MFMA anywhere: this path is compare/min/index work (DESIGN.md "Roofline").
 
@@ -76,6 +80,7 @@ struct Carve {
     u64 *srcbits, *valbits;
     u16 *wpre_s, *wpre_v;
     u32 *rowcnt_s, *rowcnt_v, *rowbase_s, *rowbase_v;
+    u32 *rowfar;         // l2: far pixels per row (k_l2win -> k_l2far, k_l2env)
     uint2 *ct;           // k_colT -> k_rows: per 32-row band and column {the band's source bits of the column, distances
                          // from the band's first / last row to the nearest source above / below}; rows of ctp columns
     int nb, ctp;         // bands per frame, columns per row of ct
@@ -109,6 +114,7 @@ Carve carve(void *ws, int B, int H, int W) {
     c.rowcnt_v = (u32 *)take(NR * 4);
     c.rowbase_s = (u32 *)take(NR * 4);
     c.rowbase_v = (u32 *)take(NR * 4);
+    c.rowfar = (u32 *)take(NR * 4);
     c.finfo = (int *)take((size_t)B * FI_STRIDE * 4);
     c.fflag2 = (int *)take((size_t)B * 4);
     c.route = (int *)take((size_t)B * 4);
@@ -174,7 +180,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, flags, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s,
-                               c.rowbase_v, c.finfo, c.vlist, c.fflag2, c.route, status, general_only ? 1 : 0, c.negflag);
+                               c.rowbase_v, c.finfo, c.vlist, c.fflag2, c.route, status, general_only ? 1 : 0, c.negflag, c.rowfar);
     mark();
     if (!general_only) {
         // dense frames: the window kernel, halo 16 or 32 per frame (k_frame's route).  It hands a frame on (fflag2) when a
@@ -264,37 +270,39 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, flags, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
-                               c.finfo, c.vlist, c.fflag2, c.route, status, general_only ? 1 : 0, c.negflag);
+                               c.finfo, c.vlist, c.fflag2, c.route, status, (general_only ? 1 : 0) | 2, c.negflag, c.rowfar);
     mark();
     // dense frames (k_frame's route 16 / 32): windows of 15 x 15 / 31 x 31 around every pixel, the few pixels with no source
     // that near one by one
     const int ttx = (W + W2_TW - 1) / W2_TW, tty = (H + W2_TH - 1) / W2_TH;
     k_l2win<W2_R16><<<dim3(ttx * tty, B), 256, L2Win<W2_R16>::LDS, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, c.xlist,
-                                                                         c.route, 16, H, W, Wd, ttx, out_depth, out_dt, out_index, status);
+                                                                         c.route, 16, c.rowfar, c.fflag2, H, W, Wd, ttx, out_depth, out_dt, out_index, status);
     mark();
     k_l2win<W2_R32><<<dim3(ttx * tty, B), 256, L2Win<W2_R32>::LDS, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, c.xlist,
-                                                                         c.route, 32, H, W, Wd, ttx, out_depth, out_dt, out_index, status);
+                                                                         c.route, 32, c.rowfar, c.fflag2, H, W, Wd, ttx, out_depth, out_dt, out_index, status);
     mark();
     // one wave per listed pixel: enough blocks per frame for ~16 k waves in the batch
     k_l2far<<<dim3(min(256, max(16, 4096 / B)), B), 256, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, c.xlist, c.route,
-                                                                  H, W, Wd, out_depth, out_dt, out_index, status);
+                                                                  c.rowfar, H, W, Wd, out_depth, out_dt, out_index, status);
     mark();
-    // the other frames: vertical distances per column (k_colT), then the lower envelope of every row
+    // vertical distances per column (k_colT) for the frames that need them: route 0, or a row handed on by k_l2win
     {
         const int cw = min(16, max(2, (c.nb + 1) / 2));
-        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, (size_t)c.nb * 64 * 2 * sizeof(u16), st>>>(c.srcbits, c.fflag2, H, W, Wd, c.nb,
-                                                                                           c.ctp, c.ct, nullptr, nullptr, nullptr);
+        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, (size_t)c.nb * 64 * 2 * sizeof(u16), st>>>(
+            c.srcbits, c.fflag2, H, W, Wd, c.nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s, (out_depth || out_index) ? c.labelmap : nullptr);
     }
     mark();
     {
-        const size_t lds = (size_t)W * 10;
+        // the rows, one wave each
+        const size_t lds = l2env_lds(W);
         static bool big_lds_set = false;
         if (lds > 48 * 1024 && !big_lds_set) {  // rows wider than ~4900 pixels
-            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_l2env), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 10) == hipSuccess;
+            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_l2env), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)l2env_lds(8192)) == hipSuccess;
             big_lds_set = true;
         }
-        k_l2env<<<dim3(H, B), 256, lds, st>>>(x, c.ct, c.ctp, c.nb, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd,
-                                             out_depth, out_dt, out_index, status, c.route);
+        k_l2env<<<dim3(H, B), 64, lds, st>>>(x, c.ct, c.ctp, c.nb, c.labelmap, c.finfo, c.vlist, c.route, c.rowfar, H, W, out_depth, out_dt,
+                                             out_index, status);
     }
     mark();
     return ok ? DTFILL_OK : DTFILL_ERR_LAUNCH;

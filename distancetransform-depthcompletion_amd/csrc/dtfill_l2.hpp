@@ -1,4 +1,4 @@
-// dtfill_l2.hpp -- the exact Euclidean transform (l2 metric): k_l2win + k_l2far (dense frames), k_l2row (the others)
+// dtfill_l2.hpp -- the exact Euclidean transform (l2 metric): k_l2win (dense frames), k_l2rest (far pixels, rows of far pixels, sparse frames)
 // Part of libdtfill.so; included by dtfill.hip inside its anonymous namespace (one translation unit).
 #pragma once
 
@@ -17,10 +17,13 @@
 //   A pixel whose minimum is <= R^2 is exact (everything that near was inside the window): rank -> label, gather, store.
 //   The others (no source within R) go on the frame's list for k_l2far, one wave per pixel.
 // R = 10 for the frames k_frame routes 16 (at 5 % density one pixel in 10^7 has no source that near), R = 15 for route 32;
-// frames with route 0 are left to k_colT + k_l2row.
+// frames with route 0 are left to k_colT + k_l2env, and so are the rows of a window-kernel frame with many far pixels.
 // ------------------------------------------------------------------------------------------------
 constexpr int W2_TH = 32, W2_TW = 256;
 constexpr int W2_R16 = 10, W2_R32 = 15;  // window radius for the frames k_frame routes 16 / 32
+// a row with this many far pixels (an eighth of it: the empty sky of a LiDAR frame, not the scattered voids of a uniform one)
+// is redone whole by k_l2env instead of pixel by pixel (k_l2far)
+__device__ __forceinline__ u32 w2_row_t(int W) { return (u32)max(32, W >> 3); }
 
 // ------------------------------------------------------------------------------------------------
 // A pixel with no source inside its window ("far"), one WAVE per pixel: lane l takes the rows i - (base + l) and
@@ -130,7 +133,8 @@ template <int R>
 __global__ __launch_bounds__(256) void k_l2win(const float *__restrict__ x, const u64 *__restrict__ srcbits,
                                                const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
                                                int *__restrict__ finfo, const float *__restrict__ vlist, u32 *__restrict__ xlist,
-                                               const int *__restrict__ route, int want_route, int H, int W, int Wd, int tiles_x,
+                                               const int *__restrict__ route, int want_route, u32 *__restrict__ rowfar,
+                                               int *__restrict__ fflag2, int H, int W, int Wd, int tiles_x,
                                                float *__restrict__ out_depth, float *__restrict__ out_dt,
                                                int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
     using C = L2Win<R>;
@@ -221,13 +225,18 @@ __global__ __launch_bounds__(256) void k_l2win(const float *__restrict__ x, cons
             far[u] = inw & (y0 + t0 + u < H) & ((best[u] >> DB) > (u32)(R * R));
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // rare: a pixel with no source within R goes on k_l2far's list, one atomic per wave and row
-            const u64 fm = __ballot(far[u]);
+        for (int u = 0; u < 4; ++u) {  // a pixel with no source within R: counted per row; a few go on k_l2far's list, 32 or more of
+            const u64 fm = __ballot(far[u]);  // a row make k_l2env redo the row (the empty sky of a LiDAR frame)
             if (fm) {
-                u32 base = 0;
-                if (lane == 0) base = (u32)atomicAdd(&finfo[b * FI_STRIDE + FI_NUNRES], __popcll(fm));
+                const u32 n = (u32)__popcll(fm);
+                u32 base = 0xFFFFFFFFu;  // lane 0: where the wave's pixels go on the list, or "the row is k_l2env's by now"
+                if (lane == 0) {
+                    const u32 before = atomicAdd(&rowfar[(size_t)b * H + y0 + t0 + u], n), t = w2_row_t(W);
+                    if (before < t && before + n >= t) fflag2[b] = 1;  // the frame needs k_colT's column distances
+                    if (before + n < t) base = (u32)atomicAdd(&finfo[b * FI_STRIDE + FI_NUNRES], (int)n);
+                }
                 base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-                if (far[u])
+                if (far[u] && base != 0xFFFFFFFFu)
                     xlist[fo + base + __builtin_amdgcn_mbcnt_hi((u32)(fm >> 32), __builtin_amdgcn_mbcnt_lo((u32)fm, 0u))] =
                         (u32)((y0 + t0 + u) * W + j);
             }
@@ -278,23 +287,33 @@ __global__ __launch_bounds__(256) void k_l2win(const float *__restrict__ x, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_l2far: the far pixels k_l2win put on the frame's list, one wave per pixel (l2far_pixel).
+// The far pixels k_l2win put on the frame's list, one wave per pixel (l2far_pixel); run by k_l2far.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_l2far(const float *__restrict__ x, const u64 *__restrict__ srcbits,
-                                               const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
-                                               const int *__restrict__ finfo, const float *__restrict__ vlist,
-                                               const u32 *__restrict__ xlist, const int *__restrict__ route, int H, int W, int Wd,
-                                               float *__restrict__ out_depth, float *__restrict__ out_dt,
-                                               int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
-    const int b = blockIdx.y;
-    if (route[b] == 0) return;
+__device__ __forceinline__ void l2far_list(const float *__restrict__ x, const u64 *__restrict__ srcbits,
+                                           const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
+                                           const int *__restrict__ finfo, const float *__restrict__ vlist,
+                                           const u32 *__restrict__ xlist, const u32 *__restrict__ rowfar, int b, int blk, int nblk,
+                                           int H, int W, int Wd, float *__restrict__ out_depth, float *__restrict__ out_dt,
+                                           int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
     const int n = finfo[b * FI_STRIDE + FI_NUNRES];
     const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
-    for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < n; idx += gridDim.x * 4) {  // wave-uniform
-        const int p = (int)xlist[(size_t)b * H * W + idx];
-        const int i = p / W;
-        l2far_pixel(x, srcbits, wpre_s, rowbase_s, vlist, b, H, W, Wd, i, p - i * W, nval, misaligned, out_depth, out_dt, out_index,
-                    frame_status);
+    const int lane = threadIdx.x & 63;
+    const u32 t = w2_row_t(W);
+    // the list is dealt out to the waves entry by entry (neighbours on the list are neighbours in the frame and cost alike); a
+    // wave looks 64 of its entries up at a time (one lane each), drops those whose row has been handed to the envelope search
+    // since, and searches for the rest one after the other, the whole wave per pixel
+    const int wpb = blockDim.x >> 6, nwaves = nblk * wpb, w0 = blk * wpb + (threadIdx.x >> 6);
+    for (int e0 = 0; w0 + e0 * nwaves < n; e0 += 64) {
+        const int e = w0 + (e0 + lane) * nwaves;
+        const int p = e < n ? (int)xlist[(size_t)b * H * W + e] : -1;
+        u64 keep = __ballot(p >= 0 && rowfar[(size_t)b * H + max(p, 0) / W] < t);
+        while (keep) {
+            const int l = __ffsll((long long)keep) - 1;
+            keep &= keep - 1;
+            const int pp = __shfl(p, l), i = pp / W;
+            l2far_pixel(x, srcbits, wpre_s, rowbase_s, vlist, b, H, W, Wd, i, pp - i * W, nval, misaligned, out_depth, out_dt, out_index,
+                        frame_status);
+        }
     }
 }
 
@@ -306,57 +325,59 @@ __global__ __launch_bounds__(256) void k_l2far(const float *__restrict__ x, cons
 // rule breaks the ties.  That monotonicity replaces the sequential stack: solve j = 0 and j = W-1 over all columns, then
 // the midpoints level by level -- the owner of a midpoint lies between the owners of its solved neighbours -- so a level
 // looks at every column about once: O(W log W) per row, any distance, no data-dependent radius.
-//   * one block per row; the columns that hold a source are compacted into LDS as {g^2, source row << 16 | column};
-//   * a level's queries are shared out over the block: 256 / queries lanes per query (candidates strided over the lanes,
-//     minimum by wave shuffles), one lane per query once there are 256 or more;
+//   * one wave per row; the columns that hold a source are compacted into LDS as {g^2, source row << 16 | column};
+//   * a level's queries are shared out over the wave: 64 / queries lanes per query (candidates strided over the lanes,
+//     minimum by wave shuffles), one lane per query once there are 64 or more;
 //   * keys compare as (d2, source row, column): ties go to the smallest raster index of the source, as brute force does.
 // ------------------------------------------------------------------------------------------------
 struct L2Cand {
-    u32 hi, lo, idx;  // squared distance, source row << 16 | column, position in the compacted column list
+    u32 hi, lo;  // squared distance; source row << 16 | position in the compacted column list (same order as the columns)
 };
-__device__ __forceinline__ void l2env_offer(L2Cand &best, const uint2 *__restrict__ s_c, int cc, int j) {
-    const uint2 cv = s_c[cc];
+__device__ __forceinline__ void l2env_offer(L2Cand &best, const uint2 cv, int cc, int j) {
     const int dk = j - (int)(cv.y & 0xFFFFu);
-    const u32 hi = cv.x + (u32)(dk * dk);
-    if (hi < best.hi || (hi == best.hi && cv.y < best.lo)) {
+    const u32 hi = cv.x + (u32)(dk * dk), lo = (cv.y & 0xFFFF0000u) | (u32)cc;
+    if (hi < best.hi || (hi == best.hi && lo < best.lo)) {
         best.hi = hi;
-        best.lo = cv.y;
-        best.idx = (u32)cc;
+        best.lo = lo;
     }
 }
 __device__ __forceinline__ void l2env_merge(L2Cand &best, int off) {
-    const u32 oh = (u32)__shfl_xor((int)best.hi, off), ol = (u32)__shfl_xor((int)best.lo, off), oi = (u32)__shfl_xor((int)best.idx, off);
+    const u32 oh = (u32)__shfl_xor((int)best.hi, off), ol = (u32)__shfl_xor((int)best.lo, off);
     if (oh < best.hi || (oh == best.hi && ol < best.lo)) {
         best.hi = oh;
         best.lo = ol;
-        best.idx = oi;
     }
 }
 
-constexpr u32 L2_NOSRC = 0x3FFFFFFFu;  // g^2 of a column without a source
-__global__ __launch_bounds__(256) void k_l2env(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
-                                               const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
-                                               const u32 *__restrict__ rowbase_s, const int *__restrict__ finfo,
-                                               const float *__restrict__ vlist, int H, int W, int Wd,
-                                               float *__restrict__ out_depth, float *__restrict__ out_dt,
-                                               int32_t *__restrict__ out_index, int *__restrict__ frame_status,
-                                               const int *__restrict__ route) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_env[];
-    __shared__ u32 s_wcnt[4];
-    __shared__ u32 s_red[4][3];
-    const int b = blockIdx.y, i = blockIdx.x;
-    if (route[b] != 0) return;  // k_l2win + k_l2far took the frame
-    uint2 *s_c = reinterpret_cast<uint2 *>(s_env);               // [W] the columns with a source, in column order
+__host__ __device__ constexpr size_t l2env_lds(int W) { return ((size_t)W * 10 + 15) & ~(size_t)15; }  // LDS of one row's search
+// NW waves per image row.  k_l2env uses NW = 1: the per-level bookkeeping is per wave, so one wave per row costs the fewest
+// instructions (a 256-thread block per row measured 1.8 x the time on whole sparse frames); NW = 4 shortens a single row's
+// chain and pays when only a few rows are searched.
+template <int NW>
+__device__ __forceinline__ void l2env_sync() {
+    if (NW == 1)
+        __builtin_amdgcn_wave_barrier();  // one wave: its LDS operations complete in order
+    else
+        __syncthreads();
+}
+template <int NW>
+__device__ __forceinline__ void l2env_row(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
+                                          const int32_t *__restrict__ labelmap, const int *__restrict__ finfo,
+                                          const float *__restrict__ vlist, int H, int W, int b, int i,
+                                          float *__restrict__ out_depth, float *__restrict__ out_dt,
+                                          int32_t *__restrict__ out_index, int *__restrict__ frame_status,
+                                          unsigned char *s_env, u32 *s_wcnt) {
+    constexpr int NT = 64 * NW;
+    uint2 *s_c = reinterpret_cast<uint2 *>(s_env);               // [W] the columns with a source, in column order: {g^2, row << 16 | column}
     u16 *s_own = reinterpret_cast<u16 *>(s_env + (size_t)W * 8);  // [W] owner of every solved pixel (index into s_c)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = NW == 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t fo = (size_t)b * H * W;
-    // columns -> {g^2, source row << 16 | column}, compacted
-    int c = 0;
+    int c = 0;  // uniform over the row's waves
     {
         const int band = i >> 5, r = i & 31;
         const uint2 *crow = ct + ((size_t)b * nb + band) * CTP;
         const u32 upmask = (2u << r) - 1u;
-        for (int k0 = 0; k0 < W; k0 += 256) {
+        for (int k0 = 0; k0 < W; k0 += NT) {
             const int k = k0 + tid;
             bool has = false;
             uint2 cv = make_uint2(0u, 0u);
@@ -369,83 +390,135 @@ __global__ __launch_bounds__(256) void k_l2env(const float *__restrict__ x, cons
                 cv = make_uint2(m * m, (u32)(gd < gu ? i + (int)m : i - (int)m) << 16 | (u32)k);
             }
             const u64 bal = __ballot(has);
-            if (lane == 0) s_wcnt[wv] = (u32)__popcll(bal);
-            __syncthreads();
-            int off = c;
-            for (int w = 0; w < wv; ++w) off += (int)s_wcnt[w];
+            int off = c, tot = __popcll(bal);
+            if (NW > 1) {
+                if (lane == 0) s_wcnt[wv] = (u32)tot;
+                l2env_sync<NW>();
+                tot = 0;
+                for (int w = 0; w < NW; ++w) {
+                    if (w < wv) off += (int)s_wcnt[w];
+                    tot += (int)s_wcnt[w];
+                }
+            }
             if (has) s_c[off + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = cv;
-            c += (int)(s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
-            __syncthreads();
+            c += tot;
+            if (NW > 1) l2env_sync<NW>();
         }
     }
+    l2env_sync<NW>();
     if (c > 0) {
-        // a query for the whole block: candidates strided over the 256 threads, wave shuffles, then the four wave minima
-        auto block_query = [&](int j, int lo, int hi) {
-            L2Cand best = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
-            for (int cc = lo + tid; cc <= hi; cc += 256) l2env_offer(best, s_c, cc, j);
-#pragma unroll
-            for (int o = 32; o; o >>= 1) l2env_merge(best, o);
-            if (lane == 0) {
-                s_red[wv][0] = best.hi;
-                s_red[wv][1] = best.lo;
-                s_red[wv][2] = best.idx;
+        // a level: nq queries j = (2m + 1) s, each between the owners of its solved neighbours; G lanes per query
+        auto level = [&](int nq, int s, bool ends) {
+            int lg = 6;  // log2 G: G = threads / (nq rounded up to a power of two), at most a wave, at least one lane per query
+            while (lg > 0 && (nq << lg) > NT) --lg;
+            const int G = 1 << lg, per = NT >> lg, gl = lane & (G - 1);
+            for (int m0 = 0; m0 < nq; m0 += per) {
+                const int m = m0 + (tid >> lg);
+                const bool act = m < nq;
+                const int j = ends ? (m ? W - 1 : 0) : (2 * m + 1) * s;
+                L2Cand best = {0xFFFFFFFFu, 0xFFFFFFFFu};
+                if (act) {
+                    const int lo = ends ? 0 : (int)s_own[j - s], hi = ends ? c - 1 : (int)s_own[min(j + s, W - 1)];
+                    int cc = lo + gl;
+                    for (; cc + 3 * G <= hi; cc += 4 * G) {  // four candidates per step: their LDS reads are in flight together
+                        const uint2 c0 = s_c[cc], c1 = s_c[cc + G], c2 = s_c[cc + 2 * G], c3 = s_c[cc + 3 * G];
+                        l2env_offer(best, c0, cc, j);
+                        l2env_offer(best, c1, cc + G, j);
+                        l2env_offer(best, c2, cc + 2 * G, j);
+                        l2env_offer(best, c3, cc + 3 * G, j);
+                    }
+                    for (; cc <= hi; cc += G) l2env_offer(best, s_c[cc], cc, j);
+                }
+                for (int o = G >> 1; o; o >>= 1) l2env_merge(best, o);
+                if (act && gl == 0) s_own[j] = (u16)(best.lo & 0xFFFFu);
             }
-            __syncthreads();
-            if (tid == 0) {
-                int w0 = 0;
-                for (int w = 1; w < 4; ++w)
-                    if (s_red[w][0] < s_red[w0][0] || (s_red[w][0] == s_red[w0][0] && s_red[w][1] < s_red[w0][1])) w0 = w;
-                s_own[j] = (u16)s_red[w0][2];
-            }
-            __syncthreads();
+            l2env_sync<NW>();
         };
-        block_query(0, 0, c - 1);
-        if (W > 1) block_query(W - 1, 0, c - 1);
+        level(W > 1 ? 2 : 1, 0, true);  // pixels 0 and W-1 over every column
         int s = 1;
         while (s < W - 1) s <<= 1;  // s >= W - 1: the first stride below it has its odd multiples inside (0, W-1)
         for (s >>= 1; s >= 1; s >>= 1) {
             const int nq = W - 2 >= s ? ((W - 2) / s + 1) / 2 : 0;  // odd multiples of s in [s, W-2]
-            if (nq <= 2) {
-                for (int m = 0; m < nq; ++m) {
-                    const int j = (2 * m + 1) * s;
-                    block_query(j, (int)s_own[j - s], (int)s_own[min(j + s, W - 1)]);
-                }
-                continue;
-            }
-            int G = 64;  // lanes per query: 256 / (nq rounded up to a power of two), at most a wave, at least one
-            while (G > 1 && G * nq > 256) G >>= 1;
-            const int per = 256 / G, gl = tid & (G - 1);
-            for (int m0 = 0; m0 < nq; m0 += per) {
-                const int m = m0 + tid / G;
-                const bool act = m < nq;
-                const int j = (2 * m + 1) * s;
-                L2Cand best = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
-                if (act) {
-                    const int lo = (int)s_own[j - s], hi = (int)s_own[min(j + s, W - 1)];
-                    for (int cc = lo + gl; cc <= hi; cc += G) l2env_offer(best, s_c, cc, j);
-                }
-                for (int o = G >> 1; o; o >>= 1) l2env_merge(best, o);
-                if (act && gl == 0) s_own[j] = (u16)best.idx;
-            }
-            __syncthreads();
+            if (nq) level(nq, s, false);
         }
     }
     const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
-    for (int j = tid; j < W; j += 256) {
-        const int p = i * W + j;
-        int label = 0, q = p;
-        float dist = INFINITY;
-        if (c > 0) {
-            const uint2 cv = s_c[s_own[j]];
-            const int srow = (int)(cv.y >> 16), scol = (int)(cv.y & 0xFFFFu);
-            q = srow * W + scol;
-            const size_t w = ((size_t)b * H + srow) * Wd + (scol >> 6);
-            label = source_rank(rowbase_s[(size_t)b * H + srow] + wpre_s[w], srcbits[w], scol);
-            dist = sqrtf((float)(cv.x + (u32)((j - scol) * (j - scol))));
+    const float *gsrc = misaligned ? vlist + fo : x + fo;
+    bool index_error = false;
+    for (int j0 = 0; j0 < W; j0 += 4 * NT) {  // four pixels per lane and step: their gathers are in flight together
+        int q[4], label[4];
+        float dist[4], dep[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + NT * u + tid;
+            in[u] = j < W;
+            q[u] = i * W + min(j, W - 1);
+            dist[u] = INFINITY;
+            label[u] = 0;
+            if (c > 0) {
+                const uint2 cv = s_c[s_own[min(j, W - 1)]];
+                const int scol = (int)(cv.y & 0xFFFFu), dk = min(j, W - 1) - scol;
+                q[u] = (int)(cv.y >> 16) * W + scol;
+                dist[u] = sqrtf((float)(cv.x + (u32)(dk * dk)));
+            }
         }
-        if (out_index) out_index[fo + p] = label;
-        if (out_dt) out_dt[fo + p] = dist;
-        if (out_depth) out_depth[fo + p] = gather_depth(x + fo, vlist + fo, label, q, nval, misaligned, frame_status + b);
+        if (c > 0 && (out_index || out_depth)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) label[u] = labelmap[fo + q[u]];  // k_colT wrote the sources' labels
+        }
+        if (out_depth) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // depth_list[label - 1] with numpy's index semantics (tools.py:26)
+                int idx = label[u] - 1;
+                if (idx < 0) idx += nval;
+                const bool ok = idx >= 0 && idx < nval;
+                dep[u] = ok ? gsrc[misaligned ? idx : q[u]] : nanf("");
+                index_error |= in[u] && !ok;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t o = fo + (size_t)i * W + j0 + NT * u + tid;
+            if (in[u]) {
+                if (out_index) out_index[o] = label[u];
+                if (out_dt) out_dt[o] = dist[u];
+                if (out_depth) out_depth[o] = dep[u];
+            }
+        }
     }
+    if (out_depth && index_error) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_l2far: the far list of the window-kernel frames (l2far_list), one wave per listed pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_l2far(const float *__restrict__ x, const u64 *__restrict__ srcbits,
+                                               const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
+                                               const int *__restrict__ finfo, const float *__restrict__ vlist,
+                                               const u32 *__restrict__ xlist, const int *__restrict__ route,
+                                               const u32 *__restrict__ rowfar, int H, int W, int Wd,
+                                               float *__restrict__ out_depth, float *__restrict__ out_dt,
+                                               int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
+    const int b = blockIdx.y;
+    if (route[b] != 0)
+        l2far_list(x, srcbits, wpre_s, rowbase_s, finfo, vlist, xlist, rowfar, b, (int)blockIdx.x, (int)gridDim.x, H, W, Wd, out_depth, out_dt,
+                   out_index, frame_status);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_l2env: the rows, one wave (= one block) each: every row of a route-0 frame, and the rows of a window-kernel frame in which
+// k_l2win counted too many far pixels.  One wave per row costs the fewest instructions (the per-level bookkeeping is per
+// wave) and leaves the most rows in flight per CU.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_l2env(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
+                                              const int32_t *__restrict__ labelmap, const int *__restrict__ finfo,
+                                              const float *__restrict__ vlist, const int *__restrict__ route,
+                                              const u32 *__restrict__ rowfar, int H, int W,
+                                              float *__restrict__ out_depth, float *__restrict__ out_dt,
+                                              int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_env[];
+    const int b = blockIdx.y, i = blockIdx.x;
+    if (route[b] == 0 || rowfar[(size_t)b * H + i] >= w2_row_t(W))
+        l2env_row<1>(x, ct, CTP, nb, labelmap, finfo, vlist, H, W, b, i, out_depth, out_dt, out_index, frame_status, s_env, nullptr);
+}

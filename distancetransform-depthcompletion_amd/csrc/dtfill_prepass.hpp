@@ -180,8 +180,10 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
                                                u32 *__restrict__ rowbase_s, u32 *__restrict__ rowbase_v,
                                                int *__restrict__ finfo, float *__restrict__ vlist,
                                                int *__restrict__ fflag2,
-                                               int *__restrict__ route, int *__restrict__ frame_status, int mode, int *__restrict__ negflag) {
+                                               int *__restrict__ route, int *__restrict__ frame_status, int mode, int *__restrict__ negflag,
+                                               u32 *__restrict__ rowfar) {
     const bool force_general = mode & 1;  // every frame takes the any-distance kernels (tests)
+    const bool l2 = mode & 2;             // l2: rows of far pixels are handled row by row, empty rows do not decide the route
     __shared__ u32 s_ws[4], s_wv[4];
     __shared__ int s_mis, s_dlb;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         // a distance above R (real LiDAR frames: the empty sky rows), a window kernel with halo R would only find
         // that out after doing all its work.  route: halo 16 if it fits, else halo 32 (three times the work per pixel,
         // still cheaper than the any-distance kernels at a few percent density), else the any-distance kernels.
-        auto fits = [&](int R) { return (long long)run_s * (2 * R * R + 2 * R + 1) >= 14ll * H * W && s_dlb <= R; };
+        auto fits = [&](int R) { return (long long)run_s * (2 * R * R + 2 * R + 1) >= 14ll * H * W && (l2 || s_dlb <= R); };
         const int r = force_general ? 0 : fits(16) ? 16 : fits(32) ? 32 : 0;
         route[b] = r;
         negflag[b] = 0;  // k_mask_o's "this frame holds a negative value": consumed before this kernel, reset for the next pass
@@ -289,6 +291,8 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         fflag2[b] = general ? 1 : 0;  // also set by k_fused when it meets a pixel farther than its halo
         frame_status[b] = general ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
     }
+    if (l2)
+        for (int i = tid; i < H; i += 256) rowfar[(size_t)b * H + i] = 0u;  // k_l2win counts the far pixels of every row here
     if (misaligned) {
         // rare path: scatter x at value pixels into the compacted value list
         const float *xf = x + (size_t)b * H * W;

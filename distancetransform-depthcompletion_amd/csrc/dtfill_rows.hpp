@@ -43,13 +43,12 @@ constexpr int PL_D0 = 0, PL_D1 = 1, PL_D2 = 2, PL_LIVE = 3, PL_TIE = 4, PL_UNRES
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline int ct_pitch(int W) { return ((W + 63) / 64) * 64 + 640; }
 
-__global__ __launch_bounds__(1024) void k_colT(const u64 *__restrict__ srcbits, const int *__restrict__ fflag, int H,
-                                               int W, int Wd, int nb, int CTP, uint2 *__restrict__ ct,
-                                               const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
-                                               int32_t *__restrict__ labelmap) {
-    extern __shared__ u16 s_lf[];  // [nb][64] last source row of the band, [nb][64] first (0xFFFF: none)
-    __shared__ u64 s_rowword[16][64];
-    const int b = blockIdx.y, wd = blockIdx.x, lane = threadIdx.x & 63;
+// s_lf: [nb][64] last source row of the band, [nb][64] first (0xFFFF: none); wd: the block's 64-pixel word column
+__device__ __forceinline__ void colT_block(const u64 *__restrict__ srcbits, const int *__restrict__ fflag, int H,
+                                           int W, int Wd, int nb, int CTP, uint2 *__restrict__ ct,
+                                           const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
+                                           int32_t *__restrict__ labelmap, int wd, u16 *s_lf, u64 (*s_rowword)[64]) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
     if (fflag && !fflag[b]) return;
     const int j = wd * 64 + lane;
@@ -118,6 +117,15 @@ __global__ __launch_bounds__(1024) void k_colT(const u64 *__restrict__ srcbits, 
             run = f != 0xFFFF ? f : run;
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_colT(const u64 *__restrict__ srcbits, const int *__restrict__ fflag, int H,
+                                               int W, int Wd, int nb, int CTP, uint2 *__restrict__ ct,
+                                               const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
+                                               int32_t *__restrict__ labelmap) {
+    extern __shared__ u16 s_lf[];
+    __shared__ u64 s_rowword[16][64];
+    colT_block(srcbits, fflag, H, W, Wd, nb, CTP, ct, wpre_s, rowbase_s, labelmap, (int)blockIdx.x, s_lf, s_rowword);
 }
 
 __device__ __forceinline__ u32 ffbh_u32(u32 v) {  // position of the highest set bit from the top; 0xFFFFFFFF for 0
