@@ -148,14 +148,19 @@ const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_colT", "
 // predicates see outlier_removal(x) (k_mask_o, then its exhaustive variant for the frames that hold a negative value)
 void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, float val_thr, const Carve &c, unsigned flags,
                  hipStream_t st) {
-    if (flags & DTFILL_FLAG_OUTLIER_REMOVAL) {
-        k_mask_o<false><<<dim3((H + 3) / 4, B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v,
-                                                              c.rowcnt_s, c.rowcnt_v, c.negflag);
-        k_mask_o<true><<<dim3((H + 3) / 4, B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v,
-                                                             c.rowcnt_s, c.rowcnt_v, c.negflag);
-    } else if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-        k_mask4<<<dim3((H + 3) / 4, B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s,
-                                                      c.wpre_v, c.rowcnt_s, c.rowcnt_v);
+    const bool vec = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const dim3 g4((H + 3) / 4, B);
+    if ((flags & DTFILL_FLAG_OUTLIER_REMOVAL) && vec) {
+        k_mask4<1><<<g4, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v, c.negflag);
+        k_mask4<2><<<g4, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v, c.negflag);
+    } else if (flags & DTFILL_FLAG_OUTLIER_REMOVAL) {
+        k_mask_o<false><<<g4, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v,
+                                            c.negflag);
+        k_mask_o<true><<<g4, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v,
+                                           c.negflag);
+    } else if (vec)
+        k_mask4<0><<<g4, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v,
+                                       c.negflag);
     else
         k_mask<<<dim3((H + 4 * M_RPW - 1) / (4 * M_RPW), B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits,
                                                                           c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s,

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_outlier(const float *__restrict__ x, in
     }
 }
 
-// the 25 taps of pixel (i, j) straight from the frame (neighbouring rows: cache hits)
+// the 25 taps of pixel (i, j) straight from the frame (neighbouring rows: cache hits); declared in dtfill_prepass.hpp for k_mask4
 __device__ __forceinline__ bool outlier_at(const float *__restrict__ xf, int H, int W, int i, int j, float v) {
     float acc = 0.0f;
     int cnt = 0;

@@ -109,13 +109,23 @@ __device__ __forceinline__ u64 row_word(u32 nib, int lane) {
     return (lane & 8) ? ((u64)part << 32 | other) : ((u64)other << 32 | part);
 }
 
+// OM != 0: outlier_removal() (data_read.py:103-128) in front of the predicates, see dtfill_outlier.hpp: the candidates of the
+// 2048 pixels in registers (v > 1.0; every pixel when OM == 2) are listed in LDS, one lane each gathers a candidate's 25 taps,
+// and the pixels it removes read as 0.0f below.  OM == 1 raises negflag[b] on a negative value, the OM == 2 launch redoes
+// exactly those frames.
+__device__ __forceinline__ bool outlier_at(const float *__restrict__ xf, int H, int W, int i, int j, float v);
+template <int OM>
 __global__ __launch_bounds__(256) void k_mask4(const float *__restrict__ x, int H, int W, int Wd, float src_thr,
                                                float val_thr, u64 *__restrict__ srcbits, u64 *__restrict__ valbits,
                                                u16 *__restrict__ wpre_s, u16 *__restrict__ wpre_v,
-                                               u32 *__restrict__ rowcnt_s, u32 *__restrict__ rowcnt_v) {
+                                               u32 *__restrict__ rowcnt_s, u32 *__restrict__ rowcnt_v, int *__restrict__ negflag) {
+    __shared__ u16 s_list[OM ? 4 : 1][OM ? M4_NC * 256 : 1];
+    __shared__ u32 s_drop[OM ? 4 : 1][OM ? M4_NC * 8 : 1];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = blockIdx.x * 4 + wave, b = blockIdx.y;
     if (i >= H) return;
+    if (OM == 2 && !negflag[b]) return;
+    bool neg = false;
     const float4 *row = reinterpret_cast<const float4 *>(x + ((size_t)b * H + i) * W);
     const size_t wrow = ((size_t)b * H + i) * Wd;
     const int w_in_chunk = lane >> 4;  // which of the chunk's four words this lane's row builds
@@ -128,12 +138,42 @@ __global__ __launch_bounds__(256) void k_mask4(const float *__restrict__ x, int 
             const int px = ((c0 + u) << 8) + 4 * lane;
             v[u] = (c0 + u < nchunk && px < W) ? row[px >> 2] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
+        if (OM) {
+            if (lane < M4_NC * 8) s_drop[wave][lane] = 0u;
+            int n = 0;  // wave-uniform
+#pragma unroll
+            for (int u = 0; u < M4_NC; ++u) {
+                if (c0 + u >= nchunk) break;
+                const int px = ((c0 + u) << 8) + 4 * lane;
+                const float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    neg |= px < W && f[q] < 0.0f;
+                    const bool cand = px < W && (OM == 2 || f[q] > 1.0f);
+                    const u64 bal = __ballot(cand);
+                    if (cand) s_list[wave][n + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (u16)((u << 8) + 4 * lane + q);
+                    n += __popcll(bal);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float *xf = x + (size_t)b * H * W;
+            for (int t = lane; t < n; t += 64) {
+                const int jr = s_list[wave][t], j = (c0 << 8) + jr;
+                if (outlier_at(xf, H, W, i, j, xf[(size_t)i * W + j])) atomicOr(&s_drop[wave][jr >> 5], 1u << (jr & 31));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int u = 0; u < M4_NC; ++u) {
             if (c0 + u >= nchunk) break;  // wave-uniform
             const int px = ((c0 + u) << 8) + 4 * lane;
             const bool in = px < W;  // W % 4 == 0: a lane's four pixels are inside or outside together
-            const float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            if (OM) {
+                const u32 d = s_drop[wave][(u << 3) + (lane >> 3)] >> ((4 * lane) & 31);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f[q] = ((d >> q) & 1u) ? 0.0f : f[q];
+            }
             u32 ns = 0, nv = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -161,6 +201,7 @@ __global__ __launch_bounds__(256) void k_mask4(const float *__restrict__ x, int 
             run_v += v0 + v1 + v2 + v3;
         }
     }
+    if (OM == 1 && __any(neg) && lane == 0) negflag[b] = 1;  // this frame is redone by the exhaustive launch
     if (lane == 0) {
         rowcnt_s[(size_t)b * H + i] = run_s;
         rowcnt_v[(size_t)b * H + i] = run_v | (mis ? 0x80000000u : 0u);

@@ -11,10 +11,14 @@ l = json.load(open("gpurun_out/bench_default.json"))
 print("headline", l["value"], "fps", l["ms_per_step"], "ms", l["roofline"]["kernel_ms"], l["repeat"])
 for k, v in l["workloads"].items():
     print(k, v["value"], "fps", v["ms_per_step"], "ms", v["roofline"]["kernel_ms"])
+for k, v in l["l2"].items():
+    print("l2", k, v["value"], "fps", v["ms_per_step"], "ms", v["roofline"]["kernel_ms"])
 print("e2e", l["end_to_end"], "cpu", l["cpu_baseline"]["value"], l["cpu_baseline"]["single_thread"], l["cpu_baseline"]["cores"])
 PY
 timeout -k 10 900 bash scripts/profile_round.sh ${TAG:-r02} > gpurun_out/profile_round.log 2>&1 || { tail -5 gpurun_out/profile_round.log; exit 1; }
 grep "== pass" gpurun_out/profile_round.log
+METRIC=l2 timeout -k 10 900 bash scripts/profile_round.sh ${TAG:-r02} > gpurun_out/profile_round_l2.log 2>&1 || { tail -5 gpurun_out/profile_round_l2.log; exit 1; }
+grep "== pass" gpurun_out/profile_round_l2.log
 timeout -k 10 300 python bench.py --metric l2 --no-cpu-baseline --no-extras > gpurun_out/bench_l2.json 2> gpurun_out/bench_l2.err || { tail -3 gpurun_out/bench_l2.err; exit 1; }
 python -c "import json; l=json.load(open('gpurun_out/bench_l2.json')); print('l2', l['value'], 'fps', l['ms_per_step'], 'ms', l['roofline']['kernel_ms'])"
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG:-r02}/l2/trace -- python3 $GRAFT_REPO_ROOT/bench.py --metric l2 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG:-r02}/l2_trace.log 2>&1) && cp $(find gpurun_out/prof_${TAG:-r02}/l2/trace -name "*kernel_stats.csv" | head -1) gpurun_out/prof_${TAG:-r02}/l2_kernel_stats.csv && rm -rf gpurun_out/prof_${TAG:-r02}/l2
+timeout -k 10 120 python scripts/bench_outlier.py > gpurun_out/bench_outlier.txt 2>&1; tail -2 gpurun_out/bench_outlier.txt

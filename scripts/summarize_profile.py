@@ -21,8 +21,8 @@ def rows(pattern):
 
 
 def short(n):
-    m = re.search(r"(k_[a-zA-Z0-9_]+)(<\d+>)?", n)  # k_l2win<10> keeps its radius, k_rows<8, 256> is k_rows
-    return (m.group(1) + (m.group(2) or "")) if m else None
+    m = re.search(r"(k_l2win<\d+>|k_[a-zA-Z0-9_]+)", n)  # k_l2win<10> keeps its radius, k_rows<8, 256> is k_rows
+    return m.group(1) if m else None
 
 
 print("== %s: rocprofv3 --kernel-trace --stats (mean duration per launch, us) ==" % wl)
