@@ -80,7 +80,7 @@ struct Carve {
     u64 *srcbits, *valbits;
     u16 *wpre_s, *wpre_v;
     u32 *rowcnt_s, *rowcnt_v, *rowbase_s, *rowbase_v;
-    u32 *rowfar;         // l2: far pixels per row (k_l2win -> k_l2far, k_l2env)
+    u32 *rowfar;         // per row: l1_cv: k_fused left a pixel undecided (-> k_rows, k_fin, k_tiesx); l2: far pixels (k_l2win -> k_l2far, k_l2env)
     uint2 *ct;           // k_colT -> k_rows: per 32-row band and column {the band's source bits of the column, distances
                          // from the band's first / last row to the nearest source above / below}; rows of ctp columns
     int nb, ctp;         // bands per frame, columns per row of ct
@@ -114,9 +114,9 @@ Carve carve(void *ws, int B, int H, int W) {
     c.rowcnt_v = (u32 *)take(NR * 4);
     c.rowbase_s = (u32 *)take(NR * 4);
     c.rowbase_v = (u32 *)take(NR * 4);
-    c.rowfar = (u32 *)take(NR * 4);
     c.finfo = (int *)take((size_t)B * FI_STRIDE * 4);
     c.fflag2 = (int *)take((size_t)B * 4);
+    c.rowfar = (u32 *)take(NR * 4);  // right behind fflag2: rowflag_of()
     c.route = (int *)take((size_t)B * 4);
     c.status = (int *)take((size_t)B * 4);
     c.negflag = (int *)take((size_t)B * 4);
@@ -225,7 +225,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const dim3 grid(H, B);
 #define LAUNCH_ROWS(PPL_, MAXT_)                                                                                      \
     k_rows<PPL_, MAXT_><<<grid, 64 * nwv, 0, st>>>(c.ct, c.ctp, c.fflag2, H, W, nb, Wp, c.planes, c.plane_bytes, dt,    \
-                                                   fin ? c.spix : nullptr, ovec)
+                                                   fin ? c.spix : nullptr, ovec, c.rowfar)
         if (ten && nwv <= 4)
             LAUNCH_ROWS(10, 256);
         else if (ten)
@@ -241,10 +241,10 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
             const int vec = (W & 3) == 0 && aligned(out_depth, 16) && aligned(out_index, 16);
             k_fin<<<dim3(ttx * tty, B), Q_NT, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, Wd, ttx, c.spix, x, c.labelmap,
                                                        c.vlist, out_depth, out_index, status, c.finfo,
-                                                       c.xlist, c.xptr, c.planes + PL_UNRES * c.plane_bytes, vec, ep, c.dscratch);
+                                                       c.xlist, c.xptr, c.planes + PL_UNRES * c.plane_bytes, vec, ep, c.dscratch, c.rowfar);
             mark();
             k_tiesx<<<dim3(XL_BLOCKS, B), 256, 0, st>>>(c.planes + PL_UNRES * c.plane_bytes, Wp, c.fflag2, c.finfo, c.xlist,
-                                                        c.xptr, H, W, out_depth, out_index, ep, c.dscratch);
+                                                        c.xptr, H, W, out_depth, out_index, ep, c.dscratch, c.rowfar);
             mark();
         } else {
             mark();

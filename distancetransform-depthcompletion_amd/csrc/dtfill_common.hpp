@@ -41,3 +41,11 @@ struct DepthEpilogue {
 __device__ __forceinline__ float depth_epilogue(float d, const DepthEpilogue &ep) {
     return ep.use_floor ? __fadd_rn(fmaxf(__fsub_rn(d, ep.floor_), 0.0f), ep.floor_) : d;
 }
+
+// The per-row flags (l1_cv: "k_fused left a pixel of this row undecided"; l2: far pixels counted by k_l2win) live in the
+// workspace right behind the per-frame flags (carve(): fflag2, then rowfar), so that k_fused needs no pointer of its own
+// for something it touches once in a blue moon.  B = frames of the batch (gridDim.y of every kernel here).
+__host__ __device__ inline size_t rowflag_offset_bytes(int B) { return ((size_t)B * 4 + 255) & ~(size_t)255; }
+__device__ __forceinline__ u32 *rowflag_of(int *fflag, int B) {
+    return reinterpret_cast<u32 *>(reinterpret_cast<char *>(fflag) + rowflag_offset_bytes(B));
+}

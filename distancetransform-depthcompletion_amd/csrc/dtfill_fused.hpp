@@ -123,7 +123,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     int W, int th, int tw, int r0, int c0, int wr0, int wc0, int sh, const float *__restrict__ x,
     const float *__restrict__ vlist,
     const int *__restrict__ finfo, float *__restrict__ out_depth, float *__restrict__ out_dt,
-    int32_t *__restrict__ out_index, int *__restrict__ frame_status, const DepthEpilogue ep) {
+    int32_t *__restrict__ out_index, int *__restrict__ frame_status, const DepthEpilogue ep, int *__restrict__ fflag) {
     // ---- P3: tile pixels: walk to the source, d, rank -> label, gather, store.  Each lane walks F_EB
     // pixels in lock-step (their LDS reads are independent, so the hop latencies overlap) and then has
     // F_EB global gathers in flight together.
@@ -183,7 +183,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             pos[e] = __mul24(FR + tr, F_P) + FR + tc;
             code[e] = s_par[pos[e]];
             ok |= (p < npx && code[e] != F_NONE) ? (1u << e) : 0u;
-            // undecidable here: the any-distance kernels take the frame
+            // undecidable here: the any-distance kernels take the pixel's row (found again below, off the common path)
             overflow |= p < npx && code[e] == F_NONE;
         }
         // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
@@ -250,7 +250,18 @@ __device__ __forceinline__ bool fused_walk_epilogue(
         p_ok = ok;
     }
     retire();
-    return overflow;
+    const bool any = __any(overflow);  // wave-uniform
+    // The rows with an undecided pixel are redone by the any-distance kernels (every pixel of them; the decided ones get the
+    // same values again).  With a depth epilogue the whole frame is (its chains may end on finished pixels whose stored
+    // depth is already cropped / floored).  Rare, so a wave that met one looks for its rows only now (s_par is still there).
+    if (any && !EPI) {
+        u32 *rowflag = rowflag_of(fflag, (int)gridDim.y);  // the workspace keeps the row flags right behind the frame flags
+        for (int p = threadIdx.x; p < npx; p += NT) {
+            const int tr = p / tw, tc = p - tr * tw;
+            if (s_par[__mul24(FR + tr, F_P) + FR + tc] == F_NONE) rowflag[(size_t)b * H + r0 + tr] = 1u;  // same-value race
+        }
+    }
+    return any;
 }
 
 // FR = halo = largest distance the window can decide.
@@ -493,17 +504,20 @@ __device__ __forceinline__ void fused_body(
     __syncthreads();
 
     const bool overflow = fused_walk_epilogue<FR, F_NT, EPI>(s_par, s_tab, s_rw, b, H, W, th, tw, r0, c0, wr0, wc0, sh, x, vlist,
-                                                        finfo, out_depth, out_dt, out_index, frame_status, ep);
-    if (overflow) {
-        fflag[b] = 1;  // same-value race: every writer stores 1, the any-distance kernels read it after this kernel
+                                                        finfo, out_depth, out_dt, out_index, frame_status, ep, fflag);
+    if (overflow && (threadIdx.x & 63) == 0) {  // wave-uniform
+        // 1: the rows marked in rowflag, 2: the whole frame.  Same-value race: every writer of a frame stores the same value,
+        // the any-distance kernels read it after this kernel
+        fflag[b] = EPI ? 2 : 1;
         atomicOr(frame_status + b, DTFILL_FRAME_GENERAL_PATH);
     }
 }
 
 // k_fused: one launch for both halos.  route[b] (k_frame): 16 / 32 = the halo that is expected to decide every pixel of
 // frame b (source density, runs of source-free rows), 0 = the any-distance kernels take the frame.  The grid is
-// sized for the halo-32 tiling (more, smaller tiles); blocks beyond a frame's own tiling exit.  A frame in which a
-// tile pixel turns out to be farther than the halo is handed to the any-distance kernels (fflag, frame_status).
+// sized for the halo-32 tiling (more, smaller tiles); blocks beyond a frame's own tiling exit.  A tile pixel that turns out
+// to be farther than the halo from every source is not stored: its ROW is handed to the any-distance kernels (rowflag,
+// fflag = 1; frame_status), which redo exactly those rows -- the empty sky of a LiDAR frame, a hole in a dense one.
 __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,

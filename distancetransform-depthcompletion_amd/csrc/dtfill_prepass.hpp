@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
                                                int *__restrict__ route, int *__restrict__ frame_status, int mode, int *__restrict__ negflag,
                                                u32 *__restrict__ rowfar) {
     const bool force_general = mode & 1;  // every frame takes the any-distance kernels (tests)
-    const bool l2 = mode & 2;             // l2: rows of far pixels are handled row by row, empty rows do not decide the route
+    const bool l2 = mode & 2;             // l2: the window kernel's cost does not grow with the distances it meets
     __shared__ u32 s_ws[4], s_wv[4];
     __shared__ int s_mis, s_dlb;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -317,23 +317,28 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         finfo[b * FI_STRIDE + FI_MISALIGNED] = misaligned;
         finfo[b * FI_STRIDE + FI_DLB] = s_dlb;
         finfo[b * FI_STRIDE + FI_NUNRES] = 0;
-        // Which kernel family takes the frame -- a speed heuristic, never a correctness condition (the window kernel
-        // itself hands on every frame in which it meets a pixel it cannot decide).  With source density p the chance
-        // that a pixel has no source within L1 distance R is about (1-p)^(2 R^2 + 2 R + 1); if the frame is expected to
-        // hold such a pixel anyway (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), or a run of source-free rows forces
-        // a distance above R (real LiDAR frames: the empty sky rows), a window kernel with halo R would only find
-        // that out after doing all its work.  route: halo 16 if it fits, else halo 32 (three times the work per pixel,
-        // still cheaper than the any-distance kernels at a few percent density), else the any-distance kernels.
+        // Which kernel family takes the frame -- a speed heuristic, never a correctness condition (the window kernels hand on
+        // every row in which they meet a pixel they cannot decide).  With source density p the chance that a pixel has no
+        // source within L1 distance R is about (1-p)^(2 R^2 + 2 R + 1); if the frame is expected to hold such pixels all
+        // over (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), a window kernel with halo R would do its work for nothing.
+        // A run of source-free rows that forces a distance above R (real LiDAR frames: the empty sky) also says no for the
+        // l1 window kernel: only those rows would be redone, but its level-by-level expansion costs the more the farther
+        // apart the sources of the other rows are (scan lines: 91 us instead of 66 at the same density) -- measured slower
+        // than the any-distance kernels on the whole frame.  The l2 window kernel does not care.
+        // route: halo 16 if it fits, else halo 32 (three times the work per pixel, still cheaper than the any-distance
+        // kernels at a few percent density), else the any-distance kernels.
         auto fits = [&](int R) { return (long long)run_s * (2 * R * R + 2 * R + 1) >= 14ll * H * W && (l2 || s_dlb <= R); };
         const int r = force_general ? 0 : fits(16) ? 16 : fits(32) ? 32 : 0;
         route[b] = r;
         negflag[b] = 0;  // k_mask_o's "this frame holds a negative value": consumed before this kernel, reset for the next pass
         const bool general = r == 0;
-        fflag2[b] = general ? 1 : 0;  // also set by k_fused when it meets a pixel farther than its halo
+        // 2: the any-distance kernels take the whole frame; k_fused sets 1 ("the rows marked in rowflag") when it meets a pixel
+        // farther than its halo, k_l2win when it hands a row of far pixels on
+        fflag2[b] = general ? 2 : 0;
         frame_status[b] = general ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
     }
-    if (l2)
-        for (int i = tid; i < H; i += 256) rowfar[(size_t)b * H + i] = 0u;  // k_l2win counts the far pixels of every row here
+    // per row: l1_cv: "k_fused left a pixel of this row undecided"; l2: far pixels k_l2win counted
+    for (int i = tid; i < H; i += 256) rowfar[(size_t)b * H + i] = 0u;
     if (misaligned) {
         // rare path: scatter x at value pixels into the compacted value list
         const float *xf = x + (size_t)b * H * W;

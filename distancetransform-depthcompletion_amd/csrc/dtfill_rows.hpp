@@ -206,17 +206,27 @@ __device__ __forceinline__ void wave_suffix_min3(u32 a, u32 b, u32 c, int lane, 
 // ------------------------------------------------------------------------------------------------
 constexpr int R_MAXWV = 16;    // W <= 8191 -> at most 16 waves of 512 columns
 constexpr int R_MAXPW = 256;   // 32-pixel words per row: W <= 8191
+// fflag[b] == 1: only the rows k_fused marked in rowflag are redone ("core" rows).  Their chains run at most Q_HOPS hops of
+// at most two rows inside k_fin, every step byte on the way needs the planes of two more rows: k_rows computes the rows
+// within R_MARGIN of a core row; everything further away keeps k_fused's results.
+constexpr int R_MARGIN = 10;
 
 template <int PPL, int MAXT>  // MAXT: 256 (rows of up to 4 waves; 3 waves per SIMD) or 1024 (any row the shape limit allows)
 __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
     const uint2 *__restrict__ ct, int CTP, const int *__restrict__ fflag, int H, int W, int nb, int Wp,
-    u8 *__restrict__ planes, size_t plane_bytes, float *__restrict__ out_dt, u32 *__restrict__ spix_out, int ovec) {
+    u8 *__restrict__ planes, size_t plane_bytes, float *__restrict__ out_dt, u32 *__restrict__ spix_out, int ovec,
+    const u32 *__restrict__ rowflag) {
     static_assert(PPL == 8 || PPL == 10, "loads and stores below are written for 8 or 10 columns per lane");
     __shared__ u32 s_tot[R_MAXWV][6];
     __shared__ u32 s_bits[5][R_MAXPW + 1];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
     const int i = blockIdx.x, b = blockIdx.y;
-    if (!fflag[b]) return;  // block-uniform
+    const int ff = fflag[b];
+    if (!ff) return;  // block-uniform
+    if (ff == 1) {    // only near a row k_fused could not finish
+        const int rr = i - R_MARGIN + lane;
+        if (!__any(lane <= 2 * R_MARGIN && rr >= 0 && rr < H && rowflag[(size_t)b * H + rr] != 0u)) return;
+    }
     const int band = i >> 5, r = i & 31;
     const int idx0 = (wv * 64 + lane) * PPL;
     const int wpr = Wp >> 2;
@@ -467,15 +477,23 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     const float *__restrict__ vlist,
     float *__restrict__ out_depth, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
     int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres, int vec,
-    const DepthEpilogue ep, float *__restrict__ dscratch) {
+    const DepthEpilogue ep, float *__restrict__ dscratch, const u32 *__restrict__ rowflag) {
     __shared__ u32 s_pl[6][Q_TH + 4][Q_RS];  // d bit 0, 1, 2, live, tie, in-image; rows r0-2 .. r0+TH+1
     __shared__ u8 s_byte[Q_TH][Q_TW];   // per tile pixel: step to its parent ((di + 2) << 3 | (dj + 2); 18 = none)
     __shared__ u32 s_unres[Q_NT];       // per tile word: tie pixels that k_tiesx finishes
     __shared__ u32 s_cnt[Q_NT / 64];
     const int b = blockIdx.y, tid = threadIdx.x;
-    if (!fflag[b]) return;
+    const int ff = fflag[b];
+    if (!ff) return;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * Q_TH, c0 = tx * Q_TW;
+    // the tile's rows that are redone: all of them, or (ff == 1) those k_fused marked; the others keep k_fused's results
+    u32 coremask = 0xFFFFFFFFu;
+    if (ff == 1) {
+        const int l = tid & 63;
+        coremask = (u32)__ballot(l < Q_TH && r0 + l < H && rowflag[(size_t)b * H + min(r0 + l, H - 1)] != 0u);
+        if (!coremask) return;  // block-uniform: every wave computes the same mask
+    }
     const int wpr = Wp >> 2;  // 32-pixel words per plane row
     const size_t rowb = (size_t)b * H;
     const u32 fo = (u32)b * (u32)(H * W);
@@ -620,13 +638,13 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     for (int it = 0; it < NRW; ++it) {
         const int rr = ewave + (Q_NT / 64) * it;
         const int i = r0 + rr;
-        const u32 inm = (s_pl[5][rr + 2][lw + 1] >> lb) & 15u;
+        const u32 inm = ((coremask >> rr) & 1u) ? (s_pl[5][rr + 2][lw + 1] >> lb) & 15u : 0u;  // a row that is not redone: as if outside
         const u32 b4 = any_tie ? *reinterpret_cast<const u32 *>(&s_byte[rr][elane * 4]) : 0x12121212u;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const u32 bb = (b4 >> (8 * u)) & 63u;
             int er = rr + (int)(bb >> 3) - 2, ec = elane * 4 + u + (int)(bb & 7u) - 2;  // one hop (none: step (0, 0))
-            if (bb != 18u && is_tie(er, ec)) {  // rare: a chain of more than one hop
+            if (bb != 18u && ((inm >> u) & 1u) && is_tie(er, ec)) {  // rare: a chain of more than one hop
                 bool open = true;
                 for (int hop = 1; hop < Q_HOPS; ++hop) {
                     if (er < 0 || er >= Q_TH || ec < 0 || ec >= Q_TW) break;  // a tie pixel of another tile: no step here
@@ -701,7 +719,7 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
 #pragma unroll
     for (int it = 0; it < NRW; ++it) {
         const int rr = ewave + (Q_NT / 64) * it;
-        const u32 inm = (s_pl[5][rr + 2][lw + 1] >> lb) & 15u;  // in-image bits of the four pixels
+        const u32 inm = ((coremask >> rr) & 1u) ? (s_pl[5][rr + 2][lw + 1] >> lb) & 15u : 0u;  // in-image bits of the four pixels
         const u32 pixb = ((u32)min(r0 + rr, H - 1) * (u32)W + (u32)col) << 2;
 #pragma unroll
         for (int u = 0; u < 4; ++u) lab[it][u] = ((nonem >> (4 * it + u)) & 1u) ? 0 : lab[it][u];
@@ -754,9 +772,10 @@ __global__ __launch_bounds__(256) void k_tiesx(const u8 *__restrict__ unres, int
                                                const int *__restrict__ finfo, const u32 *__restrict__ xlist,
                                                const u32 *__restrict__ xptr, int H, int W, float *out_depth,
                                                int32_t *out_index, const DepthEpilogue ep,
-                                               const float *__restrict__ dscratch) {
+                                               const float *__restrict__ dscratch, const u32 *__restrict__ rowflag) {
     const int b = blockIdx.y;
-    if (!fflag[b]) return;
+    const int ff = fflag[b];
+    if (!ff) return;
     const int n = finfo[b * FI_STRIDE + FI_NUNRES];
     const size_t rowb = (size_t)b * H;
     const size_t fo = (size_t)b * H * W;
@@ -772,9 +791,11 @@ __global__ __launch_bounds__(256) void k_tiesx(const u8 *__restrict__ unres, int
         u32 p = xptr[fo + q];
         for (int step = 0; step < H * W; ++step) {  // every step ends on a pixel nearer to the sources
             const u32 pi = p / (u32)W, pj = p - pi * (u32)W;
+            // a row that was not redone holds k_fused's finished pixels (and no "unresolved" bits of this pass)
+            const bool redone = ff != 1 || rowflag[rowb + pi] != 0u;
             const u32 open = (unres[(rowb + pi) * Wp + (pj >> 3)] >> (pj & 7u)) & 1u;
             const u32 nx = xptr[fo + p];  // meaningful only if open
-            if (!open) break;
+            if (!redone || !open) break;
             p = min(nx, (u32)(H * W - 1));
         }
         if (out_index) wr_i[fo + q] = rd_i[fo + p];

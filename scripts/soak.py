@@ -57,11 +57,22 @@ for t in range(n):
                 print("   frame", bb, "px", (ii, jj), "d", dt[bb, ii, jj], "got", gi[bb, ii, jj], "want", lbl[bb, ii, jj])
             os.makedirs("gpurun_out", exist_ok=True)
             np.savez_compressed("gpurun_out/mismatch_%d_%s.npz" % (t, path), x=x, got=gi, want=lbl, dt=dt)
-    if t % 5 == 0:
+    if t % 2 == 0:  # the Euclidean mode: window kernels + far list / envelope rows (auto), every row by the envelope search (general)
         d2, dt2, idx2, st2 = O.fill_batch(x, metric="l2")
-        r = op2.run(xd); torch.cuda.synchronize()
-        if not (np.array_equal(r["index"].cpu().numpy(), idx2) and np.allclose(r["dt"].cpu().numpy(), dt2, rtol=1e-6, atol=0)):
-            bad += 1; print("L2 MISMATCH case", t, (B, H, W), p)
+        for path in ("auto", "general"):
+            r = op2.run(xd, path=path); torch.cuda.synchronize()
+            if not (np.array_equal(r["index"].cpu().numpy(), idx2) and np.allclose(r["dt"].cpu().numpy(), dt2, rtol=1e-6, atol=0)
+                    and np.array_equal(r["depth"].cpu().numpy()[st2 == 0], d2[st2 == 0], equal_nan=True)):
+                bad += 1; print("L2 MISMATCH case", t, path, (B, H, W), p, "labels differ:", int((r["index"].cpu().numpy() != idx2).sum()))
+                os.makedirs("gpurun_out", exist_ok=True)
+                np.savez_compressed("gpurun_out/mismatch_l2_%d_%s.npz" % (t, path), x=x, got=r["index"].cpu().numpy(), want=idx2)
+    if t % 7 == 0 and H >= 4 and W >= 4:  # outlier_removal() in front of the predicates == the two passes composed
+        xf = np.stack([O.outlier_removal(f) for f in x]).astype(np.float32)
+        depth_f, dt_f, lbl_f, st_f = O.fill_batch(xf)
+        r = op.run(xd, outlier_removal=True); torch.cuda.synchronize()
+        if not (np.array_equal(r["index"].cpu().numpy(), lbl_f) and np.array_equal(r["dt"].cpu().numpy(), dt_f)
+                and np.array_equal(r["depth"].cpu().numpy()[st_f == 0], depth_f[st_f == 0], equal_nan=True)):
+            bad += 1; print("FUSED OUTLIER MISMATCH case", t, (B, H, W), p)
     npx += B * H * W
     if t % 25 == 0: print("case", t, "bad", bad, "%.0fs" % (time.time() - t0), flush=True)
 print("soak done:", n, "cases,", npx, "pixels, mismatches:", bad)

@@ -296,6 +296,54 @@ def test_l2_full_size_properties(pkg, oracle):
         assert np.allclose(np.sqrt(d2.astype(np.float32)), dt[b], rtol=1e-6)
 
 
+def test_rows_handed_on_by_the_window_kernel(gpu_op, oracle):
+    """A dense frame keeps the window kernel's results wherever every pixel of a row is near a source; the rows with a pixel
+    farther than the halo are redone by the any-distance kernels (k_fused's rowflag).  Frames whose undecided rows are a
+    sky on top, a band in the middle, scattered holes; tie chains that start in a redone row and end in a kept one (sources
+    on exact diagonals just inside the dense part), that cross tiles, that run longer than k_fin follows them; one batch
+    mixing such frames with plain dense and sparse ones; the depth epilogue on top (then the whole frame is redone)."""
+    import torch
+
+    rng = np.random.default_rng(77)
+
+    def dense(B, H, W, p):
+        return np.where(rng.random((B, H, W)) < p, rng.uniform(0.95, 80, (B, H, W)), 0).astype(np.float32)
+
+    for trial in range(6):
+        B, H, W = 4, int(rng.choice([200, 352, 417])), int(rng.choice([640, 1216, 1000]))
+        x = dense(B, H, W, float(rng.choice([0.04, 0.08, 0.15])))
+        top = int(rng.integers(40, 130))
+        x[0, :top] = 0                                   # sky
+        x[1, top:top + int(rng.integers(35, 90))] = 0    # a band without sources in the middle
+        for _ in range(6):                               # holes
+            i, j = int(rng.integers(0, H - 60)), int(rng.integers(0, W - 80))
+            x[2, i:i + int(rng.integers(34, 60)), j:j + int(rng.integers(34, 80))] = 0
+        x[3, :top] = 0
+        for _ in range(12):                              # a few sources in the sky, half of them with a diagonal partner
+            i, j = int(rng.integers(0, top)), int(rng.integers(0, W))
+            x[3, i, j] = 5.0
+            k = int(rng.integers(1, 30))
+            if rng.random() < 0.5 and i + k < H and j + k < W:
+                x[3, i + k, j + k] = 6.0
+        # sources on exact diagonals at the edge of the dense part: chains of tie pixels that run from the sky into kept rows
+        for j in range(20, W - 60, 97):
+            x[0, top:top + 3, j - 20:j + 60] = 0
+            x[0, top, j] = 7.0
+            x[0, top + 2, j + 2] = 8.0
+        assert_equal_to_oracle(oracle, gpu_op, x)
+    x = dense(3, 352, 1216, 0.05)
+    x[1, :120] = 0
+    x[2] = dense(1, 352, 1216, 0.0005)[0]
+    assert_equal_to_oracle(oracle, gpu_op, x)
+    got = run(gpu_op, x)
+    assert got["general"].tolist() == [False, True, True]
+    # the depth epilogue: rows from 96 on, floored
+    want = oracle.fill_batch(x)[0]
+    res = gpu_op.run(torch.from_numpy(x).to("cuda:0"), want=("depth",), depth_rows_from=96, depth_floor=0.9)
+    torch.cuda.synchronize()
+    assert np.array_equal(res["depth"].cpu().numpy(), oracle.depth_floor(want[:, 96:], 0.9))
+
+
 def assert_l2_equal_to_oracle(oracle, op2, x, st=0.1, vt=0.1, paths=("auto", "general")):
     """l2 mode through both kernel families (window + far list for dense frames, column distances + row search for
     the others): index bit-exact, distance sqrtf of the exact integer, depth through the value-list glue."""
