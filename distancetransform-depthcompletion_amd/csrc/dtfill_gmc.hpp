@@ -38,6 +38,17 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
     for (int r = wave; r < GM_TH; r += 4) {
         const int gi = r0 + r, gj = c0 + c;
         if (gi >= H || gj >= W) continue;
+        // the pixel's own weight 7 is the largest there is: with a 0 / 1 mask (DERIVED: steps 2 and 3), where the pixel itself is
+        // masked the window maximum is 7 and the centre is the only tap that reaches it -- out = v / (1e-6 + 1).  Those steps
+        // work on filled maps: (nearly) every wave takes this way out and the step is a copy.  (A caller's mask may hold any
+        // float, so the first step looks at all its taps.)
+        if (DERIVED) {
+            const float vc = s_d[(r + 3) * PW + c + 3];
+            if (vc > 0.001f) {
+                out[fo + (size_t)gi * W + gj] = __fdiv_rn(vc, __fadd_rn(0.000001f, 1.0f));
+                continue;
+            }
+        }
         float mx = 0.0f, acc = 0.0f, cnt = 0.0f;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
