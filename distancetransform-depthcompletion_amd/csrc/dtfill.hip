@@ -298,16 +298,24 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     }
     mark();
     {
-        // the rows, one wave each
-        const size_t lds = l2env_lds(W);
-        static bool big_lds_set = false;
-        if (lds > 48 * 1024 && !big_lds_set) {  // rows wider than ~4900 pixels
-            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_l2env), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)l2env_lds(8192)) == hipSuccess;
-            big_lds_set = true;
+        // the rows, one wave each; then the 32 x 32 tiles of the frames with a handful of sources, one wave each
+        const size_t wave_lds = max(l2env_lds(W), (size_t)L2_PTS_MAX * 8);
+        const int ntile = ((H + PT_T - 1) / PT_T) * ((W + PT_T - 1) / PT_T);
+        if (4 * wave_lds <= 64 * 1024) {
+            const int nrowblk = (H + 3) / 4;
+            k_l2env<4><<<dim3(nrowblk + (ntile + 3) / 4, B), 256, 4 * wave_lds, st>>>(x, c.ct, c.ctp, c.nb, c.labelmap, c.finfo, c.vlist, c.route,
+                                                                                  c.rowfar, c.xlist, H, W, nrowblk, wave_lds, 1, out_depth,
+                                                                                  out_dt, out_index, status);
+        } else {
+            static bool big_lds_set = false;
+            if (wave_lds > 48 * 1024 && !big_lds_set) {  // rows wider than ~4900 pixels
+                ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_l2env<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)l2env_lds(8192)) == hipSuccess;
+                big_lds_set = true;
+            }
+            k_l2env<1><<<dim3(H + (ntile + 7) / 8, B), 64, wave_lds, st>>>(x, c.ct, c.ctp, c.nb, c.labelmap, c.finfo, c.vlist, c.route, c.rowfar, c.xlist,
+                                                               H, W, H, wave_lds, 8, out_depth, out_dt, out_index, status);
         }
-        k_l2env<<<dim3(H, B), 64, lds, st>>>(x, c.ct, c.ctp, c.nb, c.labelmap, c.finfo, c.vlist, c.route, c.rowfar, H, W, out_depth, out_dt,
-                                             out_index, status);
     }
     mark();
     return ok ? DTFILL_OK : DTFILL_ERR_LAUNCH;
@@ -436,7 +444,10 @@ int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float
     static_assert(NK_L2 <= NK_L1, "event array");
     hipEvent_t ev[NK_L1 + 1];
     for (int k = 0; k <= nk; ++k)
-        if (hipEventCreate(&ev[k]) != hipSuccess) return DTFILL_ERR_NO_DEVICE;
+        if (hipEventCreate(&ev[k]) != hipSuccess) {
+            while (k-- > 0) (void)hipEventDestroy(ev[k]);  // nothing created so far is left behind
+            return DTFILL_ERR_NO_DEVICE;
+        }
     rc = metric == DTFILL_METRIC_L2
              ? run_l2(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags, st, ev)
              : run_l1(x, B, H, W, src_thr, val_thr, out_depth, out_dt, out_index, frame_status, workspace, flags, st,

@@ -10,6 +10,8 @@ constexpr int MAX_HW_SUM = 8192;   // cv2's Q16 INIT_DIST0 = INT_MAX>>2 caps dis
 constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_DLB = 3;  // DLB: lower bound of the largest distance (empty rows)
 constexpr int FI_NUNRES = 4;  // tie pixels k_fin handed to k_tiesx (zeroed by k_frame)
 constexpr int FI_STRIDE = 8;
+constexpr int ROUTE_POINTS = -1;  // route[b]: l2, at most L2_PTS_MAX sources in the frame (k_l2pts)
+constexpr int L2_PTS_MAX = 512;
 
 // cv2 tap order (OpenCV 3.4 distanceTransformEx_5x5), forward taps 0..7; backward tap t is the
 // NEGATED forward tap t with the same weight.  Parent code = t | (backward ? 8 : 0).

@@ -34,21 +34,11 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
         }
     }
     __syncthreads();
-    const int c = lane;
-    for (int r = wave; r < GM_TH; r += 4) {
-        const int gi = r0 + r, gj = c0 + c;
-        if (gi >= H || gj >= W) continue;
-        // the pixel's own weight 7 is the largest there is: with a 0 / 1 mask (DERIVED: steps 2 and 3), where the pixel itself is
-        // masked the window maximum is 7 and the centre is the only tap that reaches it -- out = v / (1e-6 + 1).  Those steps
-        // work on filled maps: (nearly) every wave takes this way out and the step is a copy.  (A caller's mask may hold any
-        // float, so the first step looks at all its taps.)
-        if (DERIVED) {
-            const float vc = s_d[(r + 3) * PW + c + 3];
-            if (vc > 0.001f) {
-                out[fo + (size_t)gi * W + gj] = __fdiv_rn(vc, __fadd_rn(0.000001f, 1.0f));
-                continue;
-            }
-        }
+    // One pass over the 49 taps per pixel.  With a 0 / 1 mask (DERIVED: steps 2 and 3) the pixel's own weight 7 is the largest
+    // there is: where the pixel itself is masked, the window maximum is 7 and the centre is the only tap that reaches it --
+    // out = v / (1e-6 + 1).  Those steps work on filled maps, so that is most pixels; the others are listed and evaluated with
+    // every lane busy.  (A caller's mask may hold any float, so the first step looks at all taps of all pixels.)
+    auto full = [&](int r, int c) {
         float mx = 0.0f, acc = 0.0f, cnt = 0.0f;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -64,7 +54,33 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
                 mx = gt ? sv : mx;
             }
         }
-        out[fo + (size_t)gi * W + gj] = __fdiv_rn(acc, __fadd_rn(0.000001f, cnt));
+        out[fo + (size_t)(r0 + r) * W + c0 + c] = __fdiv_rn(acc, __fadd_rn(0.000001f, cnt));
+    };
+    if (!DERIVED) {
+        for (int r = wave; r < GM_TH; r += 4)
+            if (r0 + r < H && c0 + lane < W) full(r, lane);
+        return;
+    }
+    __shared__ u16 s_list[GM_TH * GM_TW];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int r = wave; r < GM_TH; r += 4) {
+        const bool in = r0 + r < H && c0 + lane < W;
+        const float vc = s_d[(r + 3) * PW + lane + 3];
+        const bool easy = in && vc > 0.001f;
+        if (easy) out[fo + (size_t)(r0 + r) * W + c0 + lane] = __fdiv_rn(vc, __fadd_rn(0.000001f, 1.0f));
+        const u64 bal = __ballot(in && !easy);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (in && !easy) s_list[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (u16)(r * GM_TW + lane);
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        const int k = s_list[t];
+        full(k / GM_TW, k % GM_TW);
     }
 }
 

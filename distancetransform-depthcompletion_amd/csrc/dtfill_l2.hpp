@@ -142,7 +142,27 @@ __global__ __launch_bounds__(256) void k_l2win(const float *__restrict__ x, cons
     constexpr int NR = C::NR, DB = C::DB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int b = blockIdx.y;
-    if (route[b] != want_route) return;
+    if (route[b] != want_route) {
+        // a frame with a handful of sources (ROUTE_POINTS): this launch's blocks, idle for it, write the list of its sources in
+        // raster order (list index = label - 1; pixel offsets) for l2pts_tile -- each block a share of the frame's bit words
+        if (R == W2_R32 && route[b] == ROUTE_POINTS) {  // (compiled into the route-32 instance only: the other one is the hot one)
+            u32 *srclist = xlist;  // such a frame has no far list: its slice of that buffer holds the source list
+            const int nwords = H * Wd, per = (nwords + (int)gridDim.x - 1) / (int)gridDim.x;
+            u32 *sl = srclist + (size_t)b * H * W;
+            for (int w = (int)blockIdx.x * per + (int)threadIdx.x; w < min(nwords, ((int)blockIdx.x + 1) * per); w += 256) {
+                u64 sb = srcbits[(size_t)b * nwords + w];
+                if (!sb) continue;
+                const int i = w / Wd, j0 = (w - i * Wd) * 64;
+                u32 k = rowbase_s[(size_t)b * H + i] + wpre_s[(size_t)b * nwords + w];
+                while (sb) {
+                    const int bit = __ffsll((long long)sb) - 1;
+                    sb &= sb - 1;
+                    sl[k++] = (u32)(i * W + j0 + bit);
+                }
+            }
+        }
+        return;
+    }
     entry_t *s_h = reinterpret_cast<entry_t *>(lds);
     uint4 *s_x = reinterpret_cast<uint4 *>(lds + C::OFF_X);
     u64 *s_w = reinterpret_cast<u64 *>(lds + C::OFF_W);
@@ -507,18 +527,130 @@ __global__ __launch_bounds__(256) void k_l2far(const float *__restrict__ x, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_l2env: the rows, one wave (= one block) each: every row of a route-0 frame, and the rows of a window-kernel frame in which
-// k_l2win counted too many far pixels.  One wave per row costs the fewest instructions (the per-level bookkeeping is per
-// wave) and leaves the most rows in flight per CU.
+// l2, a handful of sources (route ROUTE_POINTS: at most L2_PTS_MAX in the frame -- the NYU sampling patterns): one wave per
+// 32 x 32 tile.  The nearest source to a pixel p of the tile is within |p - c| + delta of p, delta = distance from the
+// tile's centre c to ITS nearest source, so it lies within delta + 2 rho of c (rho = the tile's half diagonal): the wave finds
+// delta over the frame's source list, compacts the sources inside that radius into LDS (a dozen of 200 in an NYU frame), and
+// every pixel takes the minimum of (d2, source row, source column) over them -- exact, canonical ties, no column pass at all.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_l2env(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
-                                              const int32_t *__restrict__ labelmap, const int *__restrict__ finfo,
-                                              const float *__restrict__ vlist, const int *__restrict__ route,
-                                              const u32 *__restrict__ rowfar, int H, int W,
-                                              float *__restrict__ out_depth, float *__restrict__ out_dt,
-                                              int32_t *__restrict__ out_index, int *__restrict__ frame_status) {
+constexpr int PT_T = 32;
+__device__ __forceinline__ void l2pts_tile(const float *__restrict__ x, const u32 *__restrict__ srclist,
+                                           const int *__restrict__ finfo, const float *__restrict__ vlist, int b, int H, int W,
+                                           int ty, int tx, float *__restrict__ out_depth, float *__restrict__ out_dt,
+                                           int32_t *__restrict__ out_index, int *__restrict__ frame_status, unsigned char *lds) {
+    uint2 *s_cand = reinterpret_cast<uint2 *>(lds);  // {row << 16 | column, index in the source list = label - 1}
+    const int lane = threadIdx.x & 63;
+    const size_t fo = (size_t)b * H * W;
+    const u32 *sl = srclist + fo;
+    const int nsrc = finfo[b * FI_STRIDE + FI_NSRC];
+    const int r0 = ty * PT_T, c0 = tx * PT_T;
+    // distances from the centre in doubled coordinates (the centre is at a half pixel): exact integers below 2^30
+    const int cy2 = 2 * r0 + PT_T - 1, cx2 = 2 * c0 + PT_T - 1;
+    u32 dmin = 0xFFFFFFFFu;
+    auto decode = [&](int k, u32 &rc) -> u32 {  // source k: row << 16 | column, squared distance from the centre (doubled)
+        const int p = (int)sl[k], sr = p / W, sc = p - sr * W;
+        const int dy = 2 * sr - cy2, dx = 2 * sc - cx2;
+        rc = (u32)sr << 16 | (u32)sc;
+        return (u32)(dy * dy + dx * dx);
+    };
+    for (int k = lane; k < nsrc; k += 64) {
+        u32 rc;
+        dmin = min(dmin, decode(k, rc));
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) dmin = min(dmin, (u32)__shfl_xor((int)dmin, o));
+    // |s - c| <= delta + 2 rho; doubled: 2 rho = (PT_T - 1) sqrt 2 = 43.9, twice that + a pixel of slack for the float arithmetic
+    const float reach = sqrtf((float)dmin) + 2.0f * 1.4143f * (float)(PT_T - 1) + 2.0f;
+    const float reach2 = reach * reach;
+    int n = 0;  // wave-uniform
+    for (int k0 = 0; k0 < nsrc; k0 += 64) {  // the list again (cache hits): keeping it in registers costs occupancy
+        const int k = k0 + lane;
+        u32 rc = 0u;
+        const bool keep = k < nsrc && (float)decode(k, rc) <= reach2;
+        const u64 bal = __ballot(keep);
+        if (keep) s_cand[n + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = make_uint2(rc, (u32)k);
+        n += __popcll(bal);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // a lane: one column, 16 rows of the tile
+    constexpr int NP = PT_T / 2;
+    const int j = c0 + (lane & 31), i0 = r0 + (lane >> 5) * NP;
+    unsigned long long best[NP];
+    u32 bidx[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        best[u] = ~0ull;
+        bidx[u] = 0u;
+    }
+    for (int q = 0; q < n; ++q) {
+        const uint2 cv = s_cand[q];  // the same address for every lane: a broadcast
+        const int sr = (int)(cv.x >> 16), dc = (int)(cv.x & 0xFFFFu) - j;
+        const u32 dc2 = (u32)(dc * dc);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int dr = sr - (i0 + u);
+            const unsigned long long key = (unsigned long long)((u32)(dr * dr) + dc2) << 32 | cv.x;
+            if (key < best[u]) {
+                best[u] = key;
+                bidx[u] = cv.y;
+            }
+        }
+    }
+    const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
+    const float *gsrc = misaligned ? vlist + fo : x + fo;
+    float dep[NP];
+    bool index_error = false;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {  // depth_list[label - 1] (tools.py:26): the label is >= 1 here
+        const u32 rc = (u32)best[u];
+        const int q = (int)(rc >> 16) * W + (int)(rc & 0xFFFFu);
+        const bool ok = (int)bidx[u] < nval;
+        const bool in = i0 + u < H && j < W;
+        dep[u] = (out_depth && in && ok) ? gsrc[misaligned ? (int)bidx[u] : q] : nanf("");
+        index_error |= in && !ok;
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        if (i0 + u < H && j < W) {
+            const size_t o = fo + (size_t)(i0 + u) * W + j;
+            if (out_index) out_index[o] = (int32_t)bidx[u] + 1;
+            if (out_dt) out_dt[o] = sqrtf((float)(u32)(best[u] >> 32));
+            if (out_depth) out_depth[o] = dep[u];
+        }
+    }
+    if (out_depth && index_error) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_l2env: what the window kernels left, one WAVE per unit of work (the waves of a block share nothing but the launch).
+// Blocks [0, nrowblk): rows -- every row of a route-0 frame, and the rows of a window-kernel frame in which k_l2win counted
+// too many far pixels (l2env_row: one wave per row costs the fewest instructions -- the per-level bookkeeping is per wave --
+// and leaves the most rows in flight per CU).  The blocks behind them: the 32 x 32 tiles of the frames with a handful of
+// sources (l2pts_tile).
+// ------------------------------------------------------------------------------------------------
+template <int WPB>  // waves per block, each on a unit of its own: 4 while four rows' LDS fit 64 KB (W <= 1638), else 1
+__global__ __launch_bounds__(64 * WPB, 5) void k_l2env(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
+                                                    const int32_t *__restrict__ labelmap, const int *__restrict__ finfo,
+                                                    const float *__restrict__ vlist, const int *__restrict__ route,
+                                                    const u32 *__restrict__ rowfar, const u32 *__restrict__ srclist, int H, int W,
+                                                    int nrowblk, size_t wave_lds, int tpw, float *__restrict__ out_depth,
+                                                    float *__restrict__ out_dt, int32_t *__restrict__ out_index,
+                                                    int *__restrict__ frame_status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_env[];
-    const int b = blockIdx.y, i = blockIdx.x;
-    if (route[b] == 0 || rowfar[(size_t)b * H + i] >= w2_row_t(W))
-        l2env_row<1>(x, ct, CTP, nb, labelmap, finfo, vlist, H, W, b, i, out_depth, out_dt, out_index, frame_status, s_env, nullptr);
+    const int b = blockIdx.y, wv = threadIdx.x >> 6, r = route[b];
+    unsigned char *lds = s_env + (size_t)wv * wave_lds;
+    if ((int)blockIdx.x >= nrowblk) {
+        if (r == ROUTE_POINTS) {
+            const int tiles_x = (W + PT_T - 1) / PT_T, ntile = tiles_x * ((H + PT_T - 1) / PT_T);
+            const int t0 = (((int)blockIdx.x - nrowblk) * WPB + wv) * tpw;  // tpw tiles per wave (wide frames: fewer blocks)
+            for (int t = t0; t < min(ntile, t0 + tpw); ++t) {
+                l2pts_tile(x, srclist, finfo, vlist, b, H, W, t / tiles_x, t % tiles_x, out_depth, out_dt, out_index, frame_status, lds);
+                __builtin_amdgcn_wave_barrier();  // the next tile reuses the candidate list
+            }
+        }
+        return;
+    }
+    const int i = (int)blockIdx.x * WPB + wv;
+    if (i < H && (r == 0 || (r > 0 && rowfar[(size_t)b * H + i] >= w2_row_t(W))))
+        l2env_row<1>(x, ct, CTP, nb, labelmap, finfo, vlist, H, W, b, i, out_depth, out_dt, out_index, frame_status, lds, nullptr);
 }

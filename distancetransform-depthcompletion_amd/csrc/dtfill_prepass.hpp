@@ -328,14 +328,18 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         // route: halo 16 if it fits, else halo 32 (three times the work per pixel, still cheaper than the any-distance
         // kernels at a few percent density), else the any-distance kernels.
         auto fits = [&](int R) { return (long long)run_s * (2 * R * R + 2 * R + 1) >= 14ll * H * W && (l2 || s_dlb <= R); };
-        const int r = force_general ? 0 : fits(16) ? 16 : fits(32) ? 32 : 0;
+        // l2, a handful of sources (the NYU sampling patterns): ROUTE_POINTS -- every 32 x 32 tile looks at the sources that can
+        // own one of its pixels, found by distance from the tile's centre (l2pts_tile); the blocks of k_l2win's launch
+        // write the list of sources
+        const bool points = l2 && !force_general && run_s > 0 && run_s <= (u32)L2_PTS_MAX;
+        const int r = force_general ? 0 : points ? ROUTE_POINTS : fits(16) ? 16 : fits(32) ? 32 : 0;
         route[b] = r;
         negflag[b] = 0;  // k_mask_o's "this frame holds a negative value": consumed before this kernel, reset for the next pass
         const bool general = r == 0;
         // 2: the any-distance kernels take the whole frame; k_fused sets 1 ("the rows marked in rowflag") when it meets a pixel
         // farther than its halo, k_l2win when it hands a row of far pixels on
         fflag2[b] = general ? 2 : 0;
-        frame_status[b] = general ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
+        frame_status[b] = (general || points) ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
     }
     // per row: l1_cv: "k_fused left a pixel of this row undecided"; l2: far pixels k_l2win counted
     for (int i = tid; i < H; i += 256) rowfar[(size_t)b * H + i] = 0u;

@@ -411,6 +411,41 @@ def test_l2_sparse_shapes(pkg, oracle):
     assert_l2_equal_to_oracle(oracle, op2, x)
 
 
+def test_l2_frames_with_a_handful_of_sources(pkg, oracle):
+    """l2, at most 512 sources in the frame (the NYU sampling patterns): every 32 x 32 tile takes the minimum over the sources
+    within (distance from its centre to the nearest source) + its diagonal.  512 / 513 sources (the routing boundary), all
+    sources in one corner (every tile keeps every source), one source, two sources on a diagonal (ties along a line), frames
+    smaller than a tile, a width that is no multiple of 32, values that are not sources, dense and sparse frames in one batch."""
+    op2 = pkg.device.DtFill(device="cuda:0", metric="l2")
+    rng = np.random.default_rng(314)
+
+    def pts(H, W, n, box=None):
+        f = np.zeros((H, W), np.float32)
+        r0, r1, c0, c1 = box or (0, H, 0, W)
+        pos = rng.choice((r1 - r0) * (c1 - c0), n, replace=False)
+        f[r0 + pos // (c1 - c0), c0 + pos % (c1 - c0)] = rng.uniform(0.95, 10, n)
+        return f
+
+    for n in (1, 2, 37, 512, 513):
+        assert_l2_equal_to_oracle(oracle, op2, np.stack([pts(480, 640, n), pts(480, 640, max(1, n // 2))]))
+    assert_l2_equal_to_oracle(oracle, op2, pts(300, 700, 400, box=(0, 40, 0, 60))[None])   # a cluster in one corner
+    assert_l2_equal_to_oracle(oracle, op2, pts(200, 333, 50, box=(150, 200, 300, 333))[None])
+    x = np.zeros((2, 90, 130), np.float32)
+    x[0, 10, 10] = x[0, 50, 50] = 3.0     # every pixel of the anti-diagonal band between them is a tie
+    x[1, 0, 129] = x[1, 89, 0] = 4.0
+    assert_l2_equal_to_oracle(oracle, op2, x)
+    for (H, W) in [(5, 7), (31, 33), (33, 31), (1, 100), (100, 1)]:
+        assert_l2_equal_to_oracle(oracle, op2, pts(H, W, min(3, H * W))[None])
+    x = np.stack([pts(128, 640, 60), pts(128, 640, 30)])
+    x[0, 5, :40] = 0.5                    # values that are not sources: misaligned enumerations
+    assert_l2_equal_to_oracle(oracle, op2, x)
+    mix = np.zeros((3, 128, 640), np.float32)
+    mix[0] = pts(128, 640, 100)
+    mix[1] = np.where(rng.random((128, 640)) < 0.05, rng.uniform(0.95, 80, (128, 640)), 0)
+    mix[2] = np.where(rng.random((128, 640)) < 0.004, rng.uniform(0.95, 80, (128, 640)), 0)
+    assert_l2_equal_to_oracle(oracle, op2, mix)
+
+
 def test_extreme_shapes_vs_oracle(gpu_op, oracle):
     """Shapes that stress the index arithmetic: rows wider than 4096 pixels (more than 64 bit words
     per row), tall thin frames, the largest supported H+W, and a batch with many small frames."""
