@@ -26,9 +26,9 @@ constexpr int W2_R16 = 10, W2_R32 = 15;  // window radius for the frames k_frame
 __device__ __forceinline__ u32 w2_row_t(int W) { return (u32)max(32, W >> 3); }
 
 // ------------------------------------------------------------------------------------------------
-// A pixel with no source inside its window ("far"), one WAVE per pixel: lane l takes the rows i - (base + l) and
+// A pixel with no source inside its window ("far"), one HALF WAVE per pixel: lane l takes the rows i - (base + l) and
 // i + (base + l), finds in each the nearest source left and right of the pixel's column by scanning the row's bit words,
-// and the wave reduces (d2, source row << 16 | source column) to its minimum; base advances by 64 until base^2 exceeds the
+// and the half reduces (d2, source row << 16 | source column) to its minimum; base advances by 32 until base^2 exceeds the
 // best squared distance.  Any distance, exact, canonical ties (smallest source row, then column).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void l2far_row(const u64 *__restrict__ row, int Wd, int y, int j, u32 dy2, u32 &bestd2, u32 &bestrc) {
@@ -72,32 +72,35 @@ __device__ __forceinline__ void l2far_row(const u64 *__restrict__ row, int Wd, i
     }
 }
 
-// the whole wave calls this with the same pixel p = i * W + j of frame b; lane 0 stores the three outputs
+// Two pixels per wave: lanes 0-31 search for pixel (i, j) of their half, lanes 32-63 for theirs (the two may be the same
+// pixel); lane l of a half takes the rows i - (base + l) and i + (base + l), base advancing by 32.  The first lane of each
+// half stores the three outputs.
 __device__ __forceinline__ void l2far_pixel(const float *__restrict__ x, const u64 *__restrict__ srcbits,
                                             const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
                                             const float *__restrict__ vlist, int b, int H, int W, int Wd, int i, int j,
                                             int nval, int misaligned, float *__restrict__ out_depth,
                                             float *__restrict__ out_dt, int32_t *__restrict__ out_index,
                                             int *__restrict__ frame_status) {
-    const int lane = threadIdx.x & 63;
+    const int hl = threadIdx.x & 31;
     const size_t fo = (size_t)b * H * W;
     u32 bestd2 = 0xFFFFFFFFu, bestrc = 0xFFFFFFFFu;
-    for (int base = 0; base < H; base += 64) {       // a routed frame has sources: the loop ends with a finite best
-        if ((u32)(base * base) > bestd2) break;      // base^2 == bestd2 may still hold a smaller source row
-        const int dy = base + lane;
+    for (int base = 0; base < H; base += 32) {       // a routed frame has sources: the loop ends with a finite best
+        // base^2 == bestd2 may still hold a smaller source row; the wave goes on while either half has rows to look at
+        if (!__any((u32)(base * base) <= bestd2)) break;
+        const int dy = base + hl;
         const u32 dy2 = (u32)(dy * dy);
         if (i - dy >= 0 && dy2 <= bestd2) l2far_row(srcbits + ((size_t)b * H + (i - dy)) * Wd, Wd, i - dy, j, dy2, bestd2, bestrc);
         if (dy > 0 && i + dy < H && dy2 <= bestd2) l2far_row(srcbits + ((size_t)b * H + (i + dy)) * Wd, Wd, i + dy, j, dy2, bestd2, bestrc);
-        u32 m = bestd2;  // wave minimum of (d2, row << 16 | column)
+        u32 m = bestd2;  // minimum of (d2, row << 16 | column) over the half
 #pragma unroll
-        for (int o = 32; o; o >>= 1) m = min(m, (u32)__shfl_xor((int)m, o));
+        for (int o = 16; o; o >>= 1) m = min(m, (u32)__shfl_xor((int)m, o));
         u32 r = bestd2 == m ? bestrc : 0xFFFFFFFFu;
 #pragma unroll
-        for (int o = 32; o; o >>= 1) r = min(r, (u32)__shfl_xor((int)r, o));
+        for (int o = 16; o; o >>= 1) r = min(r, (u32)__shfl_xor((int)r, o));
         bestd2 = m;
         bestrc = r;
     }
-    if (lane == 0) {
+    if (hl == 0) {
         const int p = i * W + j;
         int label = 0, q = p;
         float dist = INFINITY;
@@ -327,10 +330,12 @@ __device__ __forceinline__ void l2far_list(const float *__restrict__ x, const u6
         const int e = w0 + (e0 + lane) * nwaves;
         const int p = e < n ? (int)xlist[(size_t)b * H * W + e] : -1;
         u64 keep = __ballot(p >= 0 && rowfar[(size_t)b * H + max(p, 0) / W] < t);
-        while (keep) {
-            const int l = __ffsll((long long)keep) - 1;
+        while (keep) {  // two pixels at a time, one per half wave (the last one of an odd count twice)
+            const int l0 = __ffsll((long long)keep) - 1;
             keep &= keep - 1;
-            const int pp = __shfl(p, l), i = pp / W;
+            const int l1 = keep ? __ffsll((long long)keep) - 1 : l0;
+            keep &= keep - 1;  // (0 stays 0)
+            const int pp = __shfl(p, lane < 32 ? l0 : l1), i = pp / W;
             l2far_pixel(x, srcbits, wpre_s, rowbase_s, vlist, b, H, W, Wd, i, pp - i * W, nval, misaligned, out_depth, out_dt, out_index,
                         frame_status);
         }
