@@ -24,20 +24,76 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
     const int b = blockIdx.z, r0 = blockIdx.y * GM_TH, c0 = blockIdx.x * GM_TW;
     const size_t fo = (size_t)b * H * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ u32 s_mb[PH][4];  // bit c of a row: the mask of padded column c is not zero
+    bool odd = false;            // a mask value that is neither 0 nor 1 (only a caller's mask can hold one)
     for (int r = wave; r < PH; r += 4) {
         const int gi = r0 + r - half;
-        for (int c = lane; c < PW; c += 64) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = lane + 64 * k;
             const int gj = c0 + c - half;
-            const bool in = gi >= 0 && gi < H && gj >= 0 && gj < W;
-            s_d[r * PW + c] = in ? data[fo + (size_t)gi * W + gj] : 0.0f;
-            if (!DERIVED) s_m[r * PW + c] = in ? mask[fo + (size_t)gi * W + gj] : 0.0f;
+            const bool in = c < PW && gi >= 0 && gi < H && gj >= 0 && gj < W;
+            const float v = in ? data[fo + (size_t)gi * W + gj] : 0.0f;
+            const float m = DERIVED ? (v > 0.001f ? 1.0f : 0.0f) : (in ? mask[fo + (size_t)gi * W + gj] : 0.0f);
+            if (c < PW) {
+                s_d[r * PW + c] = v;
+                if (!DERIVED) s_m[r * PW + c] = m;
+            }
+            odd |= !(m == 0.0f || m == 1.0f);
+            const u64 bal = __ballot(m != 0.0f);
+            if (lane == 0) {
+                if (k == 0) {
+                    s_mb[r][0] = (u32)bal;
+                    s_mb[r][1] = (u32)(bal >> 32);
+                } else {
+                    s_mb[r][2] = (u32)bal;
+                    s_mb[r][3] = 0u;
+                }
+            }
         }
     }
-    __syncthreads();
-    // One pass over the 49 taps per pixel.  With a 0 / 1 mask (DERIVED: steps 2 and 3) the pixel's own weight 7 is the largest
-    // there is: where the pixel itself is masked, the window maximum is 7 and the centre is the only tap that reaches it --
-    // out = v / (1e-6 + 1).  Those steps work on filled maps, so that is most pixels; the others are listed and evaluated with
-    // every lane busy.  (A caller's mask may hold any float, so the first step looks at all taps of all pixels.)
+    const bool binary = !__syncthreads_or(odd);  // block-uniform; the tiles are staged
+    // With a 0 / 1 mask the selected taps are the masked taps at the smallest L1 distance from the pixel (w = 7 - |di| - |dj|):
+    // that distance from the rows' mask bits (nearest set bit left / right of the centre per row), then at most two taps per
+    // row, added to +0 in row-major order as the reference's reduce_sum over the 49 products does (a lone -0.0 comes out as
+    // +0.0).  No masked tap in the window: every tap ties at s = 0, all 49 are added.
+    auto ring = [&](int r, int c) {
+        u32 mbits[7];
+        u32 tmin = 64u;
+        const int w = c >> 5;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const u32 mb = __builtin_amdgcn_alignbit(s_mb[r + i][w + 1], s_mb[r + i][w], (u32)c) & 0x7Fu;  // taps j = 0..6: bits 0..6
+            mbits[i] = mb;
+            const u32 hx = min(min(ffbh_u32((mb & 0xFu) << 28), ffbl_b32(mb >> 3)), 64u);
+            tmin = min(tmin, hx + (u32)(i < 3 ? 3 - i : i - 3));
+        }
+        float acc = 0.0f, cnt = 0.0f;
+        if (tmin >= 64u) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc = __fadd_rn(acc, s_d[(r + i) * PW + c + j]);
+            cnt = 49.0f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int dx = (int)tmin - (i < 3 ? 3 - i : i - 3);
+                if (dx < 0 || dx > 3) continue;
+                if ((mbits[i] >> (3 - dx)) & 1u) {
+                    const float v = s_d[(r + i) * PW + c + 3 - dx];
+                    acc = __fadd_rn(acc, v);
+                    cnt += 1.0f;
+                }
+                if (dx > 0 && ((mbits[i] >> (3 + dx)) & 1u)) {
+                    const float v = s_d[(r + i) * PW + c + 3 + dx];
+                    acc = __fadd_rn(acc, v);
+                    cnt += 1.0f;
+                }
+            }
+        }
+        out[fo + (size_t)(r0 + r) * W + c0 + c] = __fdiv_rn(acc, __fadd_rn(0.000001f, cnt));
+    };
     auto full = [&](int r, int c) {
         float mx = 0.0f, acc = 0.0f, cnt = 0.0f;
 #pragma unroll
@@ -49,7 +105,7 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
                 const float m = DERIVED ? (v > 0.001f ? 1.0f : 0.0f) : s_m[(r + i) * PW + c + j];
                 const float sv = m * w;
                 const bool gt = sv > mx, eq = sv == mx;
-                acc = gt ? v : (eq ? __fadd_rn(acc, v) : acc);
+                acc = gt ? __fadd_rn(0.0f, v) : (eq ? __fadd_rn(acc, v) : acc);  // a new maximum restarts the sum (from +0)
                 cnt = gt ? 1.0f : (eq ? cnt + 1.0f : cnt);
                 mx = gt ? sv : mx;
             }
@@ -58,7 +114,12 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
     };
     if (!DERIVED) {
         for (int r = wave; r < GM_TH; r += 4)
-            if (r0 + r < H && c0 + lane < W) full(r, lane);
+            if (r0 + r < H && c0 + lane < W) {
+                if (binary)
+                    ring(r, lane);
+                else
+                    full(r, lane);
+            }
         return;
     }
     __shared__ u16 s_list[GM_TH * GM_TW];
@@ -80,7 +141,7 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
     const int n = s_n;
     for (int t = threadIdx.x; t < n; t += 256) {
         const int k = s_list[t];
-        full(k / GM_TW, k % GM_TW);
+        ring(k / GM_TW, k % GM_TW);
     }
 }
 

@@ -27,7 +27,7 @@ for d in sorted(glob.glob(os.path.join(src, "*", ""))):
     t["batch"] = synth.CONFIGS[name[:-3] if name.endswith("_l2") else name]["B"]
     traffic[name] = t
 json.dump(traffic, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
-for f in ("bench_default.json", "bench_l2.json", "bench_outlier.txt"):
+for f in ("bench_default.json", "bench_l2.json", "bench_outlier.txt", "bench_gmc.txt"):
     p = os.path.join(root, "gpurun_out", f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f))

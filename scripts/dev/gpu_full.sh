@@ -22,3 +22,4 @@ grep "== pass" gpurun_out/profile_round_l2.log
 timeout -k 10 300 python bench.py --metric l2 --no-cpu-baseline --no-extras > gpurun_out/bench_l2.json 2> gpurun_out/bench_l2.err || { tail -3 gpurun_out/bench_l2.err; exit 1; }
 python -c "import json; l=json.load(open('gpurun_out/bench_l2.json')); print('l2', l['value'], 'fps', l['ms_per_step'], 'ms', l['roofline']['kernel_ms'])"
 timeout -k 10 120 python scripts/bench_outlier.py > gpurun_out/bench_outlier.txt 2>&1; tail -2 gpurun_out/bench_outlier.txt
+timeout -k 10 120 python scripts/bench_gmc.py > gpurun_out/bench_gmc.txt 2>&1; tail -1 gpurun_out/bench_gmc.txt

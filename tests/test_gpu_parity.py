@@ -616,6 +616,18 @@ def test_generate_multi_channel_vs_oracle(pkg, oracle):
             if g is not None:
                 assert g.shape == x.shape and g.dtype == np.float32
                 assert np.array_equal(g, w)
+    # masks the fast 0 / 1 evaluation must not be used for (any float is a legal weight), masks that disagree with the data
+    # (masked zeros, unmasked values: "no masked tap" sums whatever is there), negative zero, a dense first step
+    x = np.where(rng.random((2, 70, 150, 1)) < 0.08, rng.uniform(1, 80, (2, 70, 150, 1)), 0).astype(np.float32)
+    for m in (np.where(x > 0, rng.choice([0.5, 1.0, 2.0, 3.5], x.shape), 0).astype(np.float32),
+              (rng.random(x.shape) < 0.05).astype(np.float32),
+              np.where(rng.random(x.shape) < 0.3, np.float32(-0.0), (x > 0.1).astype(np.float32)).astype(np.float32),
+              np.ones_like(x)):
+        xx = x.copy()
+        xx[0, 3, 5, 0] = -0.0
+        got, want = pkg.generate_multi_channel(xx, m, 7, 4), oracle.generate_multi_channel(xx, m, 7, 4)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w) and np.array_equal(np.signbit(g), np.signbit(w))
 
 
 def test_shape_errors(gpu_op, pkg):
