@@ -172,6 +172,23 @@ def test_optional_outputs_and_reuse(gpu_op, oracle):
             assert np.array_equal(got["dt"], dt)
         if "index" in want:
             assert np.array_equal(got["index"], lbl)
+    # frames with a handful of sources: the row kernel stores the finals, the tile kernel only rewrites the tie pixels -- with
+    # every subset of outputs, next to a dense frame and one whose value list is misaligned (which goes the long way)
+    x = np.zeros((4, 120, 300), np.float32)
+    for b, n in enumerate((1, 7, 60)):
+        pos = rng.choice(120 * 300, n, replace=False)
+        x[b].flat[pos] = rng.uniform(1, 80, n)
+    x[1, 40, 40] = x[1, 70, 70] = x[1, 20, 90] = x[1, 50, 60] = 3.0  # diagonal partners: whole regions of tie pixels
+    x[2, 5, :9] = 0.5                                                 # values that are not sources
+    x[3] = np.where(rng.random((120, 300)) < 0.06, rng.uniform(1, 80, (120, 300)), 0)
+    depth, dt, lbl, st = oracle.fill_batch(x)
+    assert not st.any()
+    for want in (("depth", "dt", "index"), ("depth",), ("dt",), ("index",), ("depth", "index")):
+        for path in PATHS:
+            got = run(gpu_op, x, want=want, path=path)
+            for k, ref in (("depth", depth), ("dt", dt), ("index", lbl)):
+                if k in want:
+                    assert np.array_equal(got[k], ref), (want, path, k)
 
 
 def test_reference_named_functions(pkg, oracle):
