@@ -31,4 +31,6 @@ for f in ("bench_default.json", "bench_l2.json", "bench_outlier.txt", "bench_gmc
     p = os.path.join(root, "gpurun_out", f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f))
+for f in glob.glob(os.path.join(src, "side_*_kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 print("profiles/%s:" % tag, sorted(os.listdir(dst)))
