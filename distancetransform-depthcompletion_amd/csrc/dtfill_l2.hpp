@@ -290,9 +290,9 @@ __global__ __launch_bounds__(256) void k_l2win(const float *__restrict__ x, cons
         for (int u = 0; u < 4; ++u) {
             const size_t o = fo + (size_t)(y0 + t0 + u) * W + j;
             if (S.live[u]) {
-                if (out_index) out_index[o] = S.label[u];
-                if (out_dt) out_dt[o] = S.dist[u];
-                if (out_depth) out_depth[o] = S.dep[u];
+                if (out_index) __builtin_nontemporal_store(S.label[u], &out_index[o]);
+                if (out_dt) __builtin_nontemporal_store(S.dist[u], &out_dt[o]);
+                if (out_depth) __builtin_nontemporal_store(S.dep[u], &out_depth[o]);
                 index_error |= !S.gok[u];
             }
         }
