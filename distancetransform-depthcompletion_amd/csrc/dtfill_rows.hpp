@@ -42,6 +42,8 @@ constexpr int PL_D0 = 0, PL_D1 = 1, PL_D2 = 2, PL_LIVE = 3, PL_TIE = 4, PL_UNRES
 // "no source".
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline int ct_pitch(int W) { return ((W + 63) / 64) * 64 + 640; }
+constexpr int COLT_KEEP_NB = 128;
+__host__ __device__ inline size_t colT_lds(int nb) { return (size_t)nb * 64 * (2 * sizeof(u16) + (nb <= COLT_KEEP_NB ? sizeof(u32) : 0)); }
 
 // s_lf: [nb][64] last source row of the band, [nb][64] first (0xFFFF: none); wd: the block's 64-pixel word column
 __device__ __forceinline__ void colT_block(const u64 *__restrict__ srcbits, const int *__restrict__ fflag, int H,
@@ -54,6 +56,9 @@ __device__ __forceinline__ void colT_block(const u64 *__restrict__ srcbits, cons
     const int j = wd * 64 + lane;
     const bool real = wd < Wd;  // block-uniform: word columns beyond the image only write the "no source" padding
     u16 *s_last = s_lf, *s_first = s_lf + nb * 64;
+    // up to 4096 rows the column's bits of every band fit into LDS next to them (colT_lds()): whole elements are stored
+    const bool keep_t = nb <= COLT_KEEP_NB;
+    u32 *s_t = reinterpret_cast<u32 *>(s_lf + 2 * nb * 64);
     // A wave takes 64 consecutive rows = two bands at a time; lane = row: ONE load per row brings its word (and what its
     // labels need), 64 ballots transpose the 64 x 64 bits, lane = column afterwards.
     for (int band = 2 * ch; band < nb; band += 2 * nwv) {
@@ -87,7 +92,10 @@ __device__ __forceinline__ void colT_block(const u64 *__restrict__ srcbits, cons
                 lrow[k] = (int32_t)++lab;
             }
         }
-        if (j < CTP) {
+        if (keep_t) {  // the bits wait in LDS for their {up, down}: one 8-byte store per element at the end
+            s_t[band * 64 + lane] = t_lo;
+            if (band + 1 < nb) s_t[(band + 1) * 64 + lane] = t_hi;
+        } else if (j < CTP) {
             ct[((size_t)b * nb + band) * CTP + j].x = t_lo;
             if (band + 1 < nb) ct[((size_t)b * nb + band + 1) * CTP + j].x = t_hi;
         }
@@ -100,23 +108,36 @@ __device__ __forceinline__ void colT_block(const u64 *__restrict__ srcbits, cons
         }
     }
     __syncthreads();
-    if (ch == 0) {  // distance from the band's FIRST row to the nearest source above the band (low half)
+    // The two carries are sequential over the bands: wave 0 walks down (distance from the band's FIRST row to the nearest
+    // source above the band), wave 1 walks up (from its LAST row to the nearest source below).  Each overwrites the LDS entry
+    // it has just consumed with its result, and after a barrier every (band, column) leaves as ONE 4-byte store of
+    // {up, down} -- not as two 2-byte stores by two waves at different times, which tripled the kernel's HBM traffic.
+    if (ch == 0) {
         int run = -1;
         for (int band = 0; band < nb; ++band) {
             const int up = run < 0 ? GBIG : min(band * 32 - run, GBIG);
-            if (j < CTP) reinterpret_cast<u16 *>(&ct[((size_t)b * nb + band) * CTP + j].y)[0] = (u16)up;
             const int l = s_last[band * 64 + lane];
+            s_last[band * 64 + lane] = (u16)up;
             run = l != 0xFFFF ? l : run;
         }
-    } else if (ch == 1) {  // distance from the band's LAST row to the nearest source below the band (high half)
+    } else if (ch == 1) {
         int run = -1;
         for (int band = nb - 1; band >= 0; --band) {
             const int dn = run < 0 ? GBIG : min(run - (band * 32 + 31), GBIG);
-            if (j < CTP) reinterpret_cast<u16 *>(&ct[((size_t)b * nb + band) * CTP + j].y)[1] = (u16)dn;
             const int f = s_first[band * 64 + lane];
+            s_first[band * 64 + lane] = (u16)dn;
             run = f != 0xFFFF ? f : run;
         }
     }
+    __syncthreads();
+    if (j < CTP)
+        for (int band = ch; band < nb; band += nwv) {
+            const u32 ud = (u32)s_last[band * 64 + lane] | (u32)s_first[band * 64 + lane] << 16;
+            if (keep_t)
+                ct[((size_t)b * nb + band) * CTP + j] = make_uint2(s_t[band * 64 + lane], ud);
+            else
+                ct[((size_t)b * nb + band) * CTP + j].y = ud;
+        }
 }
 
 __global__ __launch_bounds__(1024) void k_colT(const u64 *__restrict__ srcbits, const int *__restrict__ fflag, int H,
