@@ -209,7 +209,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     if (!fused_only) {
         // every other frame: argmin scans, any distance (dtfill_rows.hpp)
         const int nb = c.nb;
-        const int cw = min(16, max(2, (nb + 1) / 2));
+        const int cw = min(16, max(2, (nb + 3) / 4));  // two iterations of two bands per wave: fewer, longer waves fit the CUs in one round
         k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, colT_lds(nb), st>>>(
             c.srcbits, c.fflag2, H, W, Wd, nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s, (out_depth || out_index) ? c.labelmap : nullptr);
         mark();
@@ -292,7 +292,7 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     mark();
     // vertical distances per column (k_colT) for the frames that need them: route 0, or a row handed on by k_l2win
     {
-        const int cw = min(16, max(2, (c.nb + 1) / 2));
+        const int cw = min(16, max(2, (c.nb + 3) / 4));
         k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, colT_lds(c.nb), st>>>(
             c.srcbits, c.fflag2, H, W, Wd, c.nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s, (out_depth || out_index) ? c.labelmap : nullptr);
     }
