@@ -477,6 +477,24 @@ def test_extreme_shapes_vs_oracle(gpu_op, oracle):
     assert_equal_to_oracle(oracle, gpu_op, x, paths=("auto",))
 
 
+def test_l2_extreme_shapes_vs_oracle(pkg, oracle):
+    """The shapes of test_extreme_shapes_vs_oracle in the Euclidean mode: rows wider than 4096 pixels (the envelope search's
+    LDS beyond 48 KB, one wave per block), frames taller than 4096 rows (more than 128 bands per column), the largest supported
+    H + W with one source in a corner (distances up to 8189 in both families: far list and envelope), many small frames."""
+    op2 = pkg.device.DtFill(device="cuda:0", metric="l2")
+    rng = np.random.default_rng(32)
+    for B, H, W, p in [(1, 3, 5000, 0.01), (1, 5000, 3, 0.01), (1, 40, 8150, 0.002), (1, 8100, 90, 0.002),
+                       (70, 17, 23, 0.1), (2, 129, 4097, 0.03), (1, 300, 2000, 0.0008)]:
+        x = np.where(rng.random((B, H, W)) < p, rng.uniform(0.95, 80, (B, H, W)), 0).astype(np.float32)
+        assert_l2_equal_to_oracle(oracle, op2, x)
+    x = np.zeros((1, 100, 8091), np.float32)
+    x[0, 99, 8090] = 2.0
+    assert_l2_equal_to_oracle(oracle, op2, x)
+    x = np.where(rng.random((1, 60, 6000)) < 0.05, rng.uniform(0.95, 80, (1, 60, 6000)), 0).astype(np.float32)
+    x[0, :, 1000:5000] = 0  # a dense frame with a hole 4000 pixels wide: the far list and rows of far pixels at large distances
+    assert_l2_equal_to_oracle(oracle, op2, x)
+
+
 def test_random_fuzz_both_metrics(pkg, gpu_op, oracle):
     """Seeded fuzz over shapes, densities, thresholds and structured holes (both metrics)."""
     import torch
