@@ -204,10 +204,19 @@ def main():
         if backend != "gloo" and local_rank >= ndev:
             sys.exit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, ndev))
         torch.cuda.set_device(local_rank % ndev)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+        # the collective libraries print their connection chatter on the C-level stdout: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()  # the first collective sets the connections up
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())

@@ -10,7 +10,7 @@ or through the `dtfill_amd` alias module at the repository root.
 """
 from . import _lib
 from ._lib import METRICS, DtfillError, build, load
-from .sharding import shard_range, gather_frames, fill_sharded
+from .sharding import shard_range, gather_frames, fill_sharded, release_host_slab
 from .tools import DT_complete_batch, Distance_Transform, generate_multi_channel, nearest_point, outlier_removal
 from .postfill import Result, Result_NYU, depth_floor, depth_to_png16, kitti_rows, nyu_eval_crop
 
@@ -27,6 +27,6 @@ def __getattr__(name):
 
 __all__ = [
     "nearest_point", "DT_complete_batch", "Distance_Transform", "outlier_removal", "generate_multi_channel", "fill", "DtFill",
-    "shard_range", "gather_frames", "fill_sharded", "build", "load", "METRICS", "DtfillError",
+    "shard_range", "gather_frames", "fill_sharded", "release_host_slab", "build", "load", "METRICS", "DtfillError",
     "Result", "Result_NYU", "depth_floor", "depth_to_png16", "kitti_rows", "nyu_eval_crop",
 ]

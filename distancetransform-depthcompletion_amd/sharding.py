@@ -16,6 +16,7 @@ Errors: the reference raises IndexError once for the whole batch (tools.py:26). 
 shard, records a per-frame status in the slab, joins the barrier, and then EVERY rank raises the same IndexError
 for the first bad global frame -- no rank is left waiting in a collective.
 """
+import atexit
 import os
 from multiprocessing import shared_memory
 
@@ -86,15 +87,17 @@ class HostSlab:
         if dist is not None:
             dist.barrier(group=self.group)
 
-    def close(self):
-        """Every rank: unpin and unmap.  Rank 0 also removes the segments (call after the last reader is done)."""
+    def close(self, sync=True):
+        """Every rank: unpin and unmap.  Rank 0 also removes the segments' names (the other ranks' mappings stay valid until
+        they unmap).  sync=False skips the barrier: for error paths and interpreter exit, where the ranks may not all get here."""
         import torch
 
         for p in self._registered:
             torch.cuda.cudart().cudaHostUnregister(p)
         self._registered = []
         self.arrays, self.tensors = {}, {}
-        self.barrier()  # nobody unlinks while another rank still reads
+        if sync:
+            self.barrier()  # nobody unlinks while another rank still reads
         for s in self._shm.values():
             s.close()
             if self.rank == 0:
@@ -120,7 +123,6 @@ def gather_frames(local, n_frames, group=None, dst=None):
     slab.arrays[name][lo:hi] = local
     slab.barrier()
     out = slab.arrays[name].copy() if (dst is None or rank == dst) else None
-    slab.close()
     return out
 
 
@@ -135,6 +137,41 @@ def select_device(local_rank=None):
     dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev)
     return torch.device("cuda", dev)
+
+
+# Creating and page-locking the shared segments costs ~0.1 s for a KITTI batch of 64 frames -- far more than the fill and the
+# copies.  The slab of the last call is therefore kept and reused while batch shape, outputs and group stay the same (every
+# rank makes the same sequence of calls, so all of them keep or replace it together); a barrier at the start of a reusing call
+# keeps a fast rank from overwriting what a slow one is still copying out of the previous call.
+_slab_cache = {"key": None, "slab": None}
+
+
+def _drop_cached_slab(sync=True):
+    slab, _slab_cache["slab"], _slab_cache["key"] = _slab_cache["slab"], None, None
+    if slab is not None:
+        try:
+            slab.close(sync=sync)
+        except Exception:
+            pass
+
+
+atexit.register(_drop_cached_slab, False)
+
+
+def _cached_slab(n_frames, frame_shape, names, group):
+    key = (n_frames, tuple(frame_shape), names, id(group))
+    if _slab_cache["key"] == key:
+        _slab_cache["slab"].barrier()
+        return _slab_cache["slab"]
+    _drop_cached_slab()
+    _slab_cache["slab"] = HostSlab(n_frames, frame_shape, names, group=group)
+    _slab_cache["key"] = key
+    return _slab_cache["slab"]
+
+
+def release_host_slab():
+    """Unpin and remove the shared host slab fill_sharded keeps between calls (collective: every rank calls it)."""
+    _drop_cached_slab()
 
 
 def fill_sharded(x, src_thr=0.1, val_thr=0.1, metric="l1_cv", want=("depth", "dt", "index"),
@@ -152,7 +189,7 @@ def fill_sharded(x, src_thr=0.1, val_thr=0.1, metric="l1_cv", want=("depth", "dt
     B, H, W = x.shape
     dist, rank, world = _dist(group)
     lo, hi = shard_range(B, rank, world)
-    slab = HostSlab(B, (H, W), want, group=group)
+    slab = _cached_slab(B, (H, W), tuple(want), group)
     t0 = time.perf_counter()
     bad, out = (), None
     try:
@@ -189,8 +226,9 @@ def fill_sharded(x, src_thr=0.1, val_thr=0.1, metric="l1_cv", want=("depth", "dt
         bad = np.nonzero(slab.arrays["status"] & FRAME_INDEX_ERROR)[0] if "depth" in want else ()
         if len(bad) == 0 and (dst is None or rank == dst):
             out = {k: slab.arrays[k].copy() for k in want}  # fresh arrays, as the reference returns
-    finally:
-        slab.close()
+    except BaseException:
+        _drop_cached_slab(sync=False)  # the ranks may no longer agree on the slab's state (no collective on this path)
+        raise
     if len(bad):
         raise IndexError("frame %d: index out of bounds in depth_list[label_list-1] "
                          "(value list shorter than a label, or empty with label 0)" % int(bad[0]))
