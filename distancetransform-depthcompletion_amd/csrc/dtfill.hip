@@ -307,12 +307,9 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
                                                                                   c.rowfar, c.xlist, H, W, nrowblk, wave_lds, 1, out_depth,
                                                                                   out_dt, out_index, status);
         } else {
-            static bool big_lds_set = false;
-            if (wave_lds > 48 * 1024 && !big_lds_set) {  // rows wider than ~4900 pixels
+            if (wave_lds > 48 * 1024)  // rows wider than ~4900 pixels (set per call: the attribute belongs to the current device)
                 ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_l2env<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)l2env_lds(8192)) == hipSuccess;
-                big_lds_set = true;
-            }
             k_l2env<1><<<dim3(H + (ntile + 7) / 8, B), 64, wave_lds, st>>>(x, c.ct, c.ctp, c.nb, c.labelmap, c.finfo, c.vlist, c.route, c.rowfar, c.xlist,
                                                                H, W, H, wave_lds, 8, out_depth, out_dt, out_index, status);
         }
