@@ -11,6 +11,7 @@ import torch
 
 from . import _lib
 
+_NP_DTYPES = {"depth": np.float32, "dt": np.float32, "index": np.int32, "status": np.int32}
 WANT_ALL = ("depth", "dt", "index")
 
 
@@ -132,15 +133,37 @@ class DtFill:
                 "status": torch.empty((B,), dtype=torch.int32).pin_memory(),
             }
             self._pin_shape = (B, H, W)
-        np.copyto(self._pin_in.numpy(), xh, casting="same_kind")  # one pass: gathers strided input, casts if needed
+        # The transfers are pipelined against the host copies, a few frames at a time: while the CPU gathers the next chunk of
+        # the input into pinned memory the previous one is on its way to the device, and every chunk of an output is copied
+        # out of pinned memory while the next one is still crossing PCIe.
+        nchunk = min(B, 4)
+        cuts = [B * c // nchunk for c in range(nchunk + 1)]
+        pin_in = self._pin_in.numpy()
         with torch.cuda.device(self.device):
-            self._dev_in.copy_(self._pin_in, non_blocking=True)
+            stream = torch.cuda.current_stream(self.device)
+            for c in range(nchunk):
+                lo, hi = cuts[c], cuts[c + 1]
+                np.copyto(pin_in[lo:hi], xh[lo:hi], casting="same_kind")  # one pass: gathers strided input, casts if needed
+                self._dev_in[lo:hi].copy_(self._pin_in[lo:hi], non_blocking=True)
             res = self.run(self._dev_in, src_thr, val_thr, want, depth_rows_from=depth_rows_from, depth_floor=depth_floor,
                            outlier_removal=outlier_removal)
+            self._pin_out["status"].copy_(res["status"], non_blocking=True)
+            done = []  # (name, lo, hi, event): device -> pinned copies in flight
             for k, v in res.items():
-                self._pin_out[k][:, : v.shape[1]].copy_(v, non_blocking=True) if v.dim() == 3 else self._pin_out[k].copy_(v, non_blocking=True)
-            torch.cuda.current_stream(self.device).synchronize()
-        out = {k: (self._pin_out[k][:, : res[k].shape[1]] if res[k].dim() == 3 else self._pin_out[k]).numpy().copy() for k in res}
+                if v.dim() != 3:
+                    continue
+                for c in range(nchunk):
+                    lo, hi = cuts[c], cuts[c + 1]
+                    self._pin_out[k][lo:hi, : v.shape[1]].copy_(v[lo:hi], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    done.append((k, lo, hi, ev))
+            out = {k: np.empty(tuple(v.shape), _NP_DTYPES[k]) for k, v in res.items()}
+            for k, lo, hi, ev in done:
+                ev.synchronize()
+                out[k][lo:hi] = self._pin_out[k][lo:hi, : res[k].shape[1]].numpy()
+            stream.synchronize()
+            out["status"][...] = self._pin_out["status"].numpy()
         if "depth" in want:
             bad = np.nonzero(out["status"] & _lib.FRAME_INDEX_ERROR)[0]
             if bad.size:
