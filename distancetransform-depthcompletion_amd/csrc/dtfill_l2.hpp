@@ -505,10 +505,10 @@ __device__ __forceinline__ void l2env_row(const float *__restrict__ x, const uin
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const size_t o = fo + (size_t)i * W + j0 + NT * u + tid;
-            if (in[u]) {
-                if (out_index) out_index[o] = label[u];
-                if (out_dt) out_dt[o] = dist[u];
-                if (out_depth) out_depth[o] = dep[u];
+            if (in[u]) {  // whole 256-byte runs per store instruction, never read again in this pass: streaming stores
+                if (out_index) __builtin_nontemporal_store((int32_t)label[u], &out_index[o]);
+                if (out_dt) __builtin_nontemporal_store(dist[u], &out_dt[o]);
+                if (out_depth) __builtin_nontemporal_store(dep[u], &out_depth[o]);
             }
         }
     }
@@ -618,9 +618,9 @@ __device__ __forceinline__ void l2pts_tile(const float *__restrict__ x, const u3
     for (int u = 0; u < NP; ++u) {
         if (i0 + u < H && j < W) {
             const size_t o = fo + (size_t)(i0 + u) * W + j;
-            if (out_index) out_index[o] = (int32_t)bidx[u] + 1;
-            if (out_dt) out_dt[o] = sqrtf((float)(u32)(best[u] >> 32));
-            if (out_depth) out_depth[o] = dep[u];
+            if (out_index) __builtin_nontemporal_store((int32_t)bidx[u] + 1, &out_index[o]);
+            if (out_dt) __builtin_nontemporal_store(sqrtf((float)(u32)(best[u] >> 32)), &out_dt[o]);
+            if (out_depth) __builtin_nontemporal_store(dep[u], &out_depth[o]);
         }
     }
     if (out_depth && index_error) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);

@@ -168,6 +168,27 @@ template <typename T>
 __device__ __forceinline__ void st_off(void *base, u32 byte_off, T v) {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
+// the same as a streaming store: for outputs nothing in the pass reads again (vector types go out component-wise: the
+// builtin takes scalars and native vectors only)
+template <typename T>
+__device__ __forceinline__ void st_off_nt(void *base, u32 byte_off, T v) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    char *p = reinterpret_cast<char *>(base) + byte_off;
+    if constexpr (sizeof(T) == 16) {
+        f4 t;
+        __builtin_memcpy(&t, &v, 16);
+        __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p));
+    } else if constexpr (sizeof(T) == 8) {
+        f2 t;
+        __builtin_memcpy(&t, &v, 8);
+        __builtin_nontemporal_store(t, reinterpret_cast<f2 *>(p));
+    } else {
+        float t;
+        __builtin_memcpy(&t, &v, 4);
+        __builtin_nontemporal_store(t, reinterpret_cast<float *>(p));
+    }
+}
 __device__ __forceinline__ u32 min3u(u32 a, u32 b, u32 c) {
     u32 r;
     asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -765,8 +786,8 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
         float *dst = kept ? dp_f : ds_f;
         const u32 dpix = kept ? pixb - dcrop : pixb;
         if (vec && inm == 15u) {
-            if (ix_f) st_off(ix_f, pixb, make_int4(lab[it][0], lab[it][1], lab[it][2], lab[it][3]));
-            if (dp_f) st_off(dst, dpix, make_float4(val[it][0], val[it][1], val[it][2], val[it][3]));
+            if (ix_f) st_off_nt(ix_f, pixb, make_int4(lab[it][0], lab[it][1], lab[it][2], lab[it][3]));
+            if (dp_f) st_off_nt(dst, dpix, make_float4(val[it][0], val[it][1], val[it][2], val[it][3]));
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
