@@ -196,14 +196,23 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
             FusedTiles t;
             t.TH = (H + nty - 1) / nty;  // even split
             t.TW = (W + ntx - 1) / ntx;
+            // columns in whole 128-byte lines when the window allows it: the runs of a tile row a wave stores are then whole lines
+            if (((t.TW + 31) & ~31) <= TWM) t.TW = (t.TW + 31) & ~31;
             t.tiles_x = ntx;
             t.ntiles = ntx * nty;
             return t;
         };
         const FusedTiles t16 = tiling(16), t32 = tiling(32);
-        k_fused<<<dim3(max(t16.ntiles, t32.ntiles), B), F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W,
-                                                                      Wd, t16, t32, out_depth, out_dt, out_index, c.route,
-                                                                      c.fflag2, status, ep);
+        // streaming stores only where every run of tile pixels a wave stores is whole 128-byte lines
+        auto line = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 127) == 0; };
+        const bool stream = (W & 31) == 0 && (t16.TW & 31) == 0 && (t32.TW & 31) == 0 && line(out_depth) && line(out_dt) && line(out_index);
+        const dim3 fg(max(t16.ntiles, t32.ntiles), B);
+        if (stream)
+            k_fused<true><<<fg, F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd, t16, t32, out_depth, out_dt,
+                                               out_index, c.route, c.fflag2, status, ep);
+        else
+            k_fused<false><<<fg, F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd, t16, t32, out_depth, out_dt,
+                                                out_index, c.route, c.fflag2, status, ep);
     }
     mark();
     if (!fused_only) {

@@ -117,7 +117,7 @@ __device__ __forceinline__ void ring_store3(u32 *__restrict__ ring, int slot, in
 // P3 of the fused pass as a function of the staged window (s_par byte codes, s_rw rank half words): tile
 // pixels walk to their sources in lock-step, d, rank -> label, gather, store.  Returns whether some tile pixel
 // was undecided.  NT = threads of the calling block.
-template <int FR, int NT, bool EPI>
+template <int FR, int NT, bool EPI, bool STREAM>
 __device__ __forceinline__ bool fused_walk_epilogue(
     const u8 *__restrict__ s_par, const short *__restrict__ s_tab, const uint2 *__restrict__ s_rw, int b, int H,
     int W, int th, int tw, int r0, int c0, int wr0, int wc0, int sh, const float *__restrict__ x,
@@ -156,10 +156,19 @@ __device__ __forceinline__ bool fused_walk_epilogue(
         for (int e = 0; e < F_EB; ++e) {
             if (!((p_ok >> e) & 1u)) continue;
             // p_opix is a BYTE offset (< 2^32: a frame has < 2^26 pixels): scalar base + 32-bit vector offset
-            if (oi) *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(oi) + p_opix[e]) = p_lab[e];
-            if (ot) *reinterpret_cast<float *>(reinterpret_cast<char *>(ot) + p_opix[e]) = (float)p_dd[e];
+            // STREAM (rows of whole 128-byte lines: W % 32 == 0, aligned outputs, tile columns in whole lines): a wave's run of
+            // consecutive tile pixels is whole lines, and nothing of the outputs is read again in this pass -- streaming stores
+            // keep them from pushing the inputs out of the caches.  Otherwise the L2 has to merge the partial lines: plain stores.
+            auto put = [](auto *p, auto v) {
+                if constexpr (STREAM)
+                    __builtin_nontemporal_store(v, p);
+                else
+                    *p = v;
+            };
+            if (oi) put(reinterpret_cast<int32_t *>(reinterpret_cast<char *>(oi) + p_opix[e]), p_lab[e]);
+            if (ot) put(reinterpret_cast<float *>(reinterpret_cast<char *>(ot) + p_opix[e]), (float)p_dd[e]);
             if (od && plain) {
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(od) + p_opix[e]) = p_val[e];
+                put(reinterpret_cast<float *>(reinterpret_cast<char *>(od) + p_opix[e]), p_val[e]);
             } else if (od && p_opix[e] >= dcrop) {  // block-uniform choice: the plain pass pays nothing for the epilogue
                 *reinterpret_cast<float *>(reinterpret_cast<char *>(od) + (p_opix[e] - dcrop)) = depth_epilogue(p_val[e], ep);
             }
@@ -270,7 +279,7 @@ struct FusedTiles {
     int TH, TW, tiles_x, ntiles;
 };
 
-template <int FR, bool EPI>
+template <int FR, bool EPI, bool STREAM>
 __device__ __forceinline__ void fused_body(
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
@@ -503,7 +512,7 @@ __device__ __forceinline__ void fused_body(
     }
     __syncthreads();
 
-    const bool overflow = fused_walk_epilogue<FR, F_NT, EPI>(s_par, s_tab, s_rw, b, H, W, th, tw, r0, c0, wr0, wc0, sh, x, vlist,
+    const bool overflow = fused_walk_epilogue<FR, F_NT, EPI, STREAM>(s_par, s_tab, s_rw, b, H, W, th, tw, r0, c0, wr0, wc0, sh, x, vlist,
                                                         finfo, out_depth, out_dt, out_index, frame_status, ep, fflag);
     if (overflow && (threadIdx.x & 63) == 0) {  // wave-uniform
         // 1: the rows marked in rowflag, 2: the whole frame.  Same-value race: every writer of a frame stores the same value,
@@ -518,6 +527,7 @@ __device__ __forceinline__ void fused_body(
 // sized for the halo-32 tiling (more, smaller tiles); blocks beyond a frame's own tiling exit.  A tile pixel that turns out
 // to be farther than the halo from every source is not stored: its ROW is handed to the any-distance kernels (rowflag,
 // fflag = 1; frame_status), which redo exactly those rows -- the empty sky of a LiDAR frame, a hole in a dense one.
+template <bool STREAM>
 __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
@@ -533,7 +543,7 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const int r = route[blockIdx.y];         // block-uniform
     const bool epi = ep.row0 != 0 || ep.use_floor;  // uniform: the plain pass runs code compiled without the epilogue
 #define FUSED_CALL(FR_, EPI_, T_)                                                                                        \
-    fused_body<FR_, EPI_>(x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, T_.TH, T_.TW, T_.tiles_x, out_depth, out_dt, \
+    fused_body<FR_, EPI_, STREAM && !(EPI_)>(x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, T_.TH, T_.TW, T_.tiles_x, out_depth, out_dt, \
                           out_index, fflag, frame_status, ep, s_ring, s_rw, s_tab, s_any)
     if (r == 16 && (int)blockIdx.x < t16.ntiles) {
         if (epi)
