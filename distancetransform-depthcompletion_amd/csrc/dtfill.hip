@@ -230,10 +230,13 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const int nwv = ten ? nw10 : nw8;
         const bool fin = out_depth || out_index;  // the distance map alone needs neither sources nor tie-breaks
         float *dt = out_dt;
-        const int ovec = ten ? ((W & 1) == 0 && aligned(dt, 8)) : ((W & 3) == 0 && aligned(dt, 16));
+        // bit 0: a lane's pixels can leave as vectors; bit 1: the distance map goes through LDS and leaves as whole lines
+        const int ovec = (ten ? ((W & 1) == 0 && aligned(dt, 8)) : ((W & 3) == 0 && aligned(dt, 16))) |
+                         (((W & 31) == 0 && dt && aligned(dt, 128)) ? 2 : 0);
+        const size_t rlds = (ovec & 2) ? (size_t)W * sizeof(float) : 0;
         const dim3 grid(H, B);
 #define LAUNCH_ROWS(PPL_, MAXT_)                                                                                      \
-    k_rows<PPL_, MAXT_><<<grid, 64 * nwv, 0, st>>>(c.ct, c.ctp, c.fflag2, H, W, nb, Wp, c.planes, c.plane_bytes, dt,    \
+    k_rows<PPL_, MAXT_><<<grid, 64 * nwv, rlds, st>>>(c.ct, c.ctp, c.fflag2, H, W, nb, Wp, c.planes, c.plane_bytes, dt,    \
                                                    fin ? c.spix : nullptr, ovec, c.rowfar)
         if (ten && nwv <= 4)
             LAUNCH_ROWS(10, 256);

@@ -417,7 +417,17 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
     const u32 rob = ((u32)i * (u32)W + (u32)idx0) << 2;
     float *dt_f = out_dt ? out_dt + fo : nullptr;
     u32 *sp_f = spix_out ? spix_out + fo : nullptr;
-    if (ovec && full) {
+    // ovec bit 1: the distance map (never read again in this pass) leaves through LDS as whole 128-byte lines with streaming
+    // stores after the barrier below -- a lane's own 32 or 40 bytes are only part of a line, and the L2 would have to merge them
+    extern __shared__ __attribute__((aligned(16))) float s_dtrow[];
+    const bool dt_lds = (ovec & 2) && dt_f;
+    if (dt_lds) {
+#pragma unroll
+        for (int q = 0; q < PPL; ++q)
+            if (idx0 + q < W) s_dtrow[idx0 + q] = fd[q];
+        dt_f = nullptr;  // (the stores below skip it)
+    }
+    if ((ovec & 1) && full) {
         if (PPL == 8) {
             if (dt_f) {
                 st_off(dt_f, rob, make_float4(fd[0], fd[1], fd[2], fd[3]));
@@ -443,6 +453,11 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
         }
     }
     __syncthreads();
+    if (dt_lds) {
+        float *drow = out_dt + fo + (size_t)i * W;
+        for (int k = threadIdx.x * 4; k < W; k += blockDim.x * 4)  // W % 32 == 0
+            st_off_nt(drow, (u32)k << 2, *reinterpret_cast<const float4 *>(&s_dtrow[k]));
+    }
     for (int k = threadIdx.x; k < 5 * wpr; k += blockDim.x) {  // the row's plane words leave as whole words
         const int p = k / wpr, w = k - p * wpr;
         reinterpret_cast<u32 *>(planes + p * plane_bytes + ((size_t)b * H + i) * Wp)[w] = s_bits[p][w];
