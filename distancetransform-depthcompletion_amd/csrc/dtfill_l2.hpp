@@ -31,9 +31,13 @@ __device__ __forceinline__ u32 w2_row_t(int W) { return (u32)max(32, W >> 3); }
 // and the half reduces (d2, source row << 16 | source column) to its minimum; base advances by 32 until base^2 exceeds the
 // best squared distance.  Any distance, exact, canonical ties (smallest source row, then column).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void l2far_row(const u64 *__restrict__ row, int Wd, int y, int j, u32 dy2, u32 &bestd2, u32 &bestrc) {
+// One row of the search, in two steps so that the lanes can agree on a bound in between: FIRST only the bit word that holds
+// column j (one load; most pixels find their nearest source's neighbourhood there), REST the words left and right of it as far
+// as the bound allows.  need: bit 0 / 1 = the left / right side of this row is still open after FIRST.
+template <bool FIRST>
+__device__ __forceinline__ void l2far_row(const u64 *__restrict__ row, int Wd, int y, int j, u32 dy2, u32 &bestd2, u32 &bestrc,
+                                          u32 &need) {
     const int wj = j >> 6;
-    const u64 w0 = row[wj];
     auto offer = [&](int col) {
         const u32 d2 = dy2 + (u32)((j - col) * (j - col));
         const u32 rc = (u32)y << 16 | (u32)col;
@@ -42,32 +46,40 @@ __device__ __forceinline__ void l2far_row(const u64 *__restrict__ row, int Wd, i
             bestrc = rc;
         }
     };
-    {  // at or left of column j
-        int w = wj;
-        u64 bits = w0 & (~0ull >> (63 - (j & 63)));
-        for (;;) {
+    if (FIRST) {
+        const u64 w0 = row[wj];
+        const u64 lb = w0 & (~0ull >> (63 - (j & 63))), rb = w0 & ((~0ull << (j & 63)) << 1);
+        need = 0u;
+        if (lb)
+            offer(wj * 64 + 63 - __clzll((long long)lb));
+        else
+            need |= 1u;
+        if (rb)
+            offer(wj * 64 + __ffsll((long long)rb) - 1);
+        else
+            need |= 2u;
+        return;
+    }
+    if (need & 1u) {  // left of the word of column j
+        for (int w = wj - 1; w >= 0; --w) {
+            const u32 dm = (u32)(j - (w * 64 + 63));
+            if (dy2 + dm * dm > bestd2) break;
+            const u64 bits = row[w];
             if (bits) {
                 offer(w * 64 + 63 - __clzll((long long)bits));
                 break;
             }
-            if (--w < 0) break;
-            const u32 dm = (u32)(j - (w * 64 + 63));
-            if (dy2 + dm * dm > bestd2) break;
-            bits = row[w];
         }
     }
-    {  // right of column j
-        int w = wj;
-        u64 bits = w0 & ((~0ull << (j & 63)) << 1);
-        for (;;) {
+    if (need & 2u) {  // right of it
+        for (int w = wj + 1; w < Wd; ++w) {
+            const u32 dm = (u32)(w * 64 - j);
+            if (dy2 + dm * dm > bestd2) break;
+            const u64 bits = row[w];
             if (bits) {
                 offer(w * 64 + __ffsll((long long)bits) - 1);
                 break;
             }
-            if (++w >= Wd) break;
-            const u32 dm = (u32)(w * 64 - j);
-            if (dy2 + dm * dm > bestd2) break;
-            bits = row[w];
         }
     }
 }
@@ -89,16 +101,25 @@ __device__ __forceinline__ void l2far_pixel(const float *__restrict__ x, const u
         if (!__any((u32)(base * base) <= bestd2)) break;
         const int dy = base + hl;
         const u32 dy2 = (u32)(dy * dy);
-        if (i - dy >= 0 && dy2 <= bestd2) l2far_row(srcbits + ((size_t)b * H + (i - dy)) * Wd, Wd, i - dy, j, dy2, bestd2, bestrc);
-        if (dy > 0 && i + dy < H && dy2 <= bestd2) l2far_row(srcbits + ((size_t)b * H + (i + dy)) * Wd, Wd, i + dy, j, dy2, bestd2, bestrc);
-        u32 m = bestd2;  // minimum of (d2, row << 16 | column) over the half
+        const u64 *rup = srcbits + ((size_t)b * H + max(i - dy, 0)) * Wd, *rdn = srcbits + ((size_t)b * H + min(i + dy, H - 1)) * Wd;
+        const bool up = i - dy >= 0 && dy2 <= bestd2, dn = dy > 0 && i + dy < H && dy2 <= bestd2;
+        auto agree = [&]() {  // minimum of (d2, row << 16 | column) over the half wave
+            u32 m = bestd2;
 #pragma unroll
-        for (int o = 16; o; o >>= 1) m = min(m, (u32)__shfl_xor((int)m, o));
-        u32 r = bestd2 == m ? bestrc : 0xFFFFFFFFu;
+            for (int o = 16; o; o >>= 1) m = min(m, (u32)__shfl_xor((int)m, o));
+            u32 r = bestd2 == m ? bestrc : 0xFFFFFFFFu;
 #pragma unroll
-        for (int o = 16; o; o >>= 1) r = min(r, (u32)__shfl_xor((int)r, o));
-        bestd2 = m;
-        bestrc = r;
+            for (int o = 16; o; o >>= 1) r = min(r, (u32)__shfl_xor((int)r, o));
+            bestd2 = m;
+            bestrc = r;
+        };
+        u32 nu = 0u, nd = 0u;
+        if (up) l2far_row<true>(rup, Wd, i - dy, j, dy2, bestd2, bestrc, nu);
+        if (dn) l2far_row<true>(rdn, Wd, i + dy, j, dy2, bestd2, bestrc, nd);
+        agree();  // the bound of the half: most lanes have nothing left to look at
+        if (up && dy2 <= bestd2) l2far_row<false>(rup, Wd, i - dy, j, dy2, bestd2, bestrc, nu);
+        if (dn && dy2 <= bestd2) l2far_row<false>(rdn, Wd, i + dy, j, dy2, bestd2, bestrc, nd);
+        agree();
     }
     if (hl == 0) {
         const int p = i * W + j;
