@@ -64,6 +64,7 @@ namespace {
 #include "dtfill_prepass.hpp"
 #include "dtfill_fused.hpp"
 #include "dtfill_rows.hpp"
+#include "dtfill_sky.hpp"
 #include "dtfill_l2.hpp"
 #include "dtfill_outlier.hpp"
 #include "dtfill_gmc.hpp"
@@ -141,8 +142,8 @@ bool shape_ok(int B, int H, int W) {
            (long long)B * H * W < (1ll << 31);  // B is a grid dimension; pixel indices are 32-bit
 }
 
-constexpr int NK_L1 = 7;
-const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_colT", "k_rows", "k_fin", "k_tiesx"};
+constexpr int NK_L1 = 8;
+const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_colT", "k_rows", "k_fin", "k_tiesx", "k_sky"};
 
 // k_mask4 when the rows can be read 16 bytes at a time, k_mask otherwise (same outputs); with DTFILL_FLAG_OUTLIER_REMOVAL the
 // predicates see outlier_removal(x) (k_mask_o, then its exhaustive variant for the frames that hold a negative value)
@@ -184,13 +185,8 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     mark();
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, flags, st);
     mark();
-    k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s,
-                               c.rowbase_v, c.finfo, c.vlist, c.fflag2, c.route, status, general_only ? 1 : 0, c.negflag, c.rowfar);
-    mark();
-    if (!general_only) {
-        // dense frames: the window kernel, halo 16 or 32 per frame (k_frame's route).  It hands a frame on (fflag2) when a
-        // tile pixel turns out to be farther than the halo from every source.
-        auto tiling = [&](int R) {
+    // geometry of the window kernel's two tilings (k_frame pre-marks whole tile rows)
+    auto tiling = [&](int R) {
             const int THM = F_WHM - 2 * R, TWM = F_WWM - 2 * R;
             const int nty = (H + THM - 1) / THM, ntx = (W + TWM - 1) / TWM;
             FusedTiles t;
@@ -202,7 +198,21 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
             t.ntiles = ntx * nty;
             return t;
         };
-        const FusedTiles t16 = tiling(16), t32 = tiling(32);
+    const FusedTiles t16 = tiling(16), t32 = tiling(32);
+    const bool epi = ep.row0 != 0 || ep.use_floor;
+    // row flags (k_frame): the sky above the first source row goes to k_sky, rows too far from every source row to the
+    // any-distance kernels, the rest of the frame to the window kernel.  Not with a depth epilogue (a handed-on row costs the
+    // whole frame there) and not on the forced paths of the tests.
+    const bool rowflags = !epi && !fused_only && !general_only;
+    // k_sky takes the distances of its two base rows from the distance map: without one from the caller, the scratch frame
+    float *const out_dt_caller = out_dt;
+    if (rowflags && !out_dt) out_dt = c.dscratch;
+    k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v, c.finfo, c.vlist,
+                               c.fflag2, c.route, status, (general_only ? 1 : 0) | (rowflags ? 4 : 0), c.negflag, c.rowfar, t16.TH, t32.TH);
+    mark();
+    if (!general_only) {
+        // dense frames: the window kernel, halo 16 or 32 per frame (k_frame's route).  It hands rows on (fflag2, rowflag) when a
+        // tile pixel turns out to be farther than the halo from every source.
         // streaming stores only where every run of tile pixels a wave stores is whole 128-byte lines
         auto line = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 127) == 0; };
         const bool stream = (W & 31) == 0 && (t16.TW & 31) == 0 && (t32.TW & 31) == 0 && line(out_depth) && line(out_dt) && line(out_index);
@@ -265,6 +275,14 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     } else {
         for (int t = 0; t < 4; ++t) mark();
     }
+    if (rowflags) {
+        const size_t lds = sky_lds(sky_span_max(H, W));
+        if (lds > 48 * 1024)  // (set per call: the attribute belongs to the current device)
+            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_sky), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        k_sky<<<dim3((W + SKY_SW - 1) / SKY_SW, (H + SKY_RG - 1) / SKY_RG, B), SKY_NT, lds, st>>>(c.finfo, H, W, out_dt, out_dt_caller,
+                                                                                             out_depth, out_index);
+    }
+    mark();
     return ok ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
 
@@ -287,7 +305,7 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, flags, st);
     mark();
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
-                               c.finfo, c.vlist, c.fflag2, c.route, status, (general_only ? 1 : 0) | 2, c.negflag, c.rowfar);
+                               c.finfo, c.vlist, c.fflag2, c.route, status, (general_only ? 1 : 0) | 2, c.negflag, c.rowfar, 0, 0);
     mark();
     // dense frames (k_frame's route 16 / 32): windows of 15 x 15 / 31 x 31 around every pixel, the few pixels with no source
     // that near one by one

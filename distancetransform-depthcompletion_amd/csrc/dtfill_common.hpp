@@ -9,9 +9,17 @@ constexpr int MAX_HW_SUM = 8192;   // cv2's Q16 INIT_DIST0 = INT_MAX>>2 caps dis
 // frame facts written by k_frame: int32[FI_STRIDE] per frame
 constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_DLB = 3;  // DLB: lower bound of the largest distance (empty rows)
 constexpr int FI_NUNRES = 4;  // tie pixels k_fin handed to k_tiesx (zeroed by k_frame)
+constexpr int FI_SKY = 5;     // l1_cv: rows [0, FI_SKY) hold no source and lie above every source: k_sky's (0: none)
 constexpr int FI_STRIDE = 8;
 constexpr int ROUTE_POINTS = -1;  // route[b]: l2, at most L2_PTS_MAX sources in the frame (k_l2pts)
 constexpr int L2_PTS_MAX = 512;
+// route[b] | ROUTE_PREMARK (l1_cv): k_frame marked rows of the frame for the any-distance kernels up front (rows farther than
+// PM16 / PM32 from every row that holds a source: the window kernel with halo 16 / 32 could not decide them, or only by running
+// its level loop to the end for a handful of their pixels)
+constexpr int ROUTE_PREMARK = 0x100;
+constexpr int PM16 = 8, PM32 = 16;
+constexpr int SKY_MIN_GENERAL = 32;  // ... of a frame the any-distance kernels take whole
+constexpr int SKY_MIN = 9;  // rows above the first source row are k_sky's from this many on (fewer: within every window's reach)
 
 // cv2 tap order (OpenCV 3.4 distanceTransformEx_5x5), forward taps 0..7; backward tap t is the
 // NEGATED forward tap t with the same weight.  Parent code = t | (backward ? 8 : 0).

@@ -280,7 +280,7 @@ struct FusedTiles {
 };
 
 template <int FR, bool EPI, bool STREAM>
-__device__ __forceinline__ void fused_body(
+__device__ __forceinline__ void fused_body(bool premarked,
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
     int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
@@ -290,8 +290,30 @@ __device__ __forceinline__ void fused_body(
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int r0 = ty * TH, c0 = tx * TW;
-    const int th = min(TH, H - r0), tw = min(TW, W - c0);
+    int r0 = ty * TH;
+    const int c0 = tx * TW;
+    int th = min(TH, H - r0);
+    const int tw = min(TW, W - c0);
+    if (premarked) {
+        // k_frame handed rows of this frame to the any-distance kernels up front (the empty sky): the tile shrinks to the span
+        // of its rows that are still this kernel's; a tile without any is done.  (A row another block marks meanwhile is
+        // redone whole as well: whether this block still stores its part of it does not matter.)
+        const u32 *rowflag = rowflag_of(fflag, (int)gridDim.y) + (size_t)b * H;
+        if (tid == 0) {
+            s_any[0][0] = 0xFFFFFFFFu;
+            s_any[0][1] = 0u;
+        }
+        __syncthreads();
+        if (tid < th && rowflag[r0 + tid] == 0u) {
+            atomicMin(&s_any[0][0], (u32)tid);
+            atomicMax(&s_any[0][1], (u32)tid + 1u);
+        }
+        __syncthreads();
+        const u32 lo = s_any[0][0], hi = s_any[0][1];
+        if (hi == 0u) return;  // block-uniform
+        r0 += (int)lo;
+        th = (int)(hi - lo);
+    }
     const int wr0 = r0 - FR, wc0 = c0 - FR;  // image coords of window cell (0,0)
     const int WH = th + 2 * FR, WW = tw + 2 * FR;
     const int ca = max(0, -wc0), cb = min(WW, W - wc0);  // in-image window columns [ca, cb)
@@ -540,10 +562,12 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     __shared__ uint2 s_rw[F_WHM * 8];
     __shared__ short s_tab[64];      // s_par displacement of the step enc (0 for the codes that are no step)
     __shared__ u32 s_any[2][F_NT / 64];  // per wave: did level t produce anything (double-buffered by level parity)
-    const int r = route[blockIdx.y];         // block-uniform
+    const int rt = route[blockIdx.y];        // block-uniform
+    const int r = rt > 0 ? (rt & 0xFF) : 0;
+    const bool pre = rt > 0 && (rt & ROUTE_PREMARK);
     const bool epi = ep.row0 != 0 || ep.use_floor;  // uniform: the plain pass runs code compiled without the epilogue
 #define FUSED_CALL(FR_, EPI_, T_)                                                                                        \
-    fused_body<FR_, EPI_, STREAM && !(EPI_)>(x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, T_.TH, T_.TW, T_.tiles_x, out_depth, out_dt, \
+    fused_body<FR_, EPI_, STREAM && !(EPI_)>(pre, x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, T_.TH, T_.TW, T_.tiles_x, out_depth, out_dt, \
                           out_index, fflag, frame_status, ep, s_ring, s_rw, s_tab, s_any)
     if (r == 16 && (int)blockIdx.x < t16.ntiles) {
         if (epi)

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_outlier(const float *__restrict__ x, in
         }
         const float v = s_t[(r + 3) * (O_TW + 6) + c + 3];
         const double mean = (double)acc / ((double)cnt + 0.00001);
-        out[(size_t)b * H * W + (size_t)(r0 + r) * W + c0 + c] = ((double)v - mean) > 1.0 ? 0.0f : v;
+        out[(size_t)b * H * W + (size_t)(r0 + r) * W + c0 + c] = ((double)v - mean) > 1.0 ? v * 0.0f : v;  // data_read.py:128 multiplies by (1 - flag): a removed negative pixel is -0.0
     }
 }
 

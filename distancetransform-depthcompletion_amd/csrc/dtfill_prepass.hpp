@@ -222,9 +222,10 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
                                                int *__restrict__ finfo, float *__restrict__ vlist,
                                                int *__restrict__ fflag2,
                                                int *__restrict__ route, int *__restrict__ frame_status, int mode, int *__restrict__ negflag,
-                                               u32 *__restrict__ rowfar) {
+                                               u32 *__restrict__ rowfar, int th16, int th32) {
     const bool force_general = mode & 1;  // every frame takes the any-distance kernels (tests)
     const bool l2 = mode & 2;             // l2: the window kernel's cost does not grow with the distances it meets
+    const bool premark = mode & 4;        // l1_cv without a depth epilogue: rows too far from every source row are handed on up front
     __shared__ u32 s_ws[4], s_wv[4];
     __shared__ int s_mis, s_dlb;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -279,70 +280,148 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         __syncthreads();
     }
     if (mis) atomicOr(&s_mis, 1);
-    // Lower bound of the largest distance in the frame from runs of rows without any source: a run of k empty rows
-    // forces d >= ceil(k/2) in its middle row, d >= k at the border row if it touches the top or bottom edge.
-    // "Row has no source" as bits in LDS (H <= 8191 -> 256 words); each thread looks at the runs ENDING at its rows.
+    // Row structure of the frame (l1_cv uses all of it, l2 only FI_DLB):
+    //   r0     the first row that holds a source.  The rows above it -- the empty sky of a LiDAR frame -- need no search at all:
+    //          every source is below them, so cv2's backward sweep alone decides them, row by row from the two rows beneath
+    //          (k_sky).  Flag 2.
+    //   vd(i)  vertical distance of row i to the nearest row with a source: every pixel of row i is at least that far from
+    //          every source.  max vd = lower bound of the largest distance in the frame (FI_DLB).  A row at or below r0 with
+    //          vd above a window kernel's reach (PM16 / PM32) cannot be decided by it: it is handed to the any-distance kernels
+    //          up front (flag 1), and the window kernel takes the rest of the frame instead of nothing.
+    // "Row has no source" as bits in LDS (H <= 8191 -> 256 words); the rows past H count as empty.
+    __shared__ u32 s_empty[256];
+    __shared__ u32 s_far[2][256];  // bit i: row i >= r0 and vd(i) > PM16 / > PM32
+    __shared__ int s_nfar[2], s_r0, s_route;
     {
-        __shared__ u32 s_empty[256];
-        s_empty[tid] = 0;
+        // a wave holds 64 consecutive rows: the row bits leave as two whole words per ballot, no atomics
+        const int Hp = (H + 63) & ~63;
+        if (tid < 2) s_nfar[tid] = 0;
+        if (tid == 0) s_r0 = H;
+        for (int w = tid + (Hp >> 5); w < 256; w += 256) s_empty[w] = 0xFFFFFFFFu;
         __syncthreads();
-        for (int i = tid; i < H; i += 256)
-            if (cs_[i] == 0) atomicOr(&s_empty[i >> 5], 1u << (i & 31));
+        for (int base = 0; base < Hp; base += 256) {
+            const int i = base + tid;
+            const u64 has = __ballot(i < H && cs_[min(i, H - 1)] != 0), bal = ~has;  // empty, or past the frame
+            if (lane == 0 && i < Hp) {
+                s_empty[i >> 5] = (u32)bal;
+                s_empty[(i >> 5) + 1] = (u32)(bal >> 32);
+                if (has) atomicMin(&s_r0, i + __ffsll((long long)has) - 1);
+            }
+        }
         __syncthreads();
         int dlb = 0;
-        for (int i = tid; i < H; i += 256) {
-            const bool e = (s_empty[i >> 5] >> (i & 31)) & 1u;
-            const bool enext = i + 1 < H && ((s_empty[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u);
-            if (!e || enext) continue;  // not the last row of a run
-            // first row of the run of set bits that ends at row i: whole words at a time
-            int w = i >> 5, start;
-            const u32 zeros_below = ~s_empty[w] & ((2u << (i & 31)) - 1u);  // cleared bits at or below bit i of this word
-            if (zeros_below) {
-                start = w * 32 + 32 - __clz((int)zeros_below);
-            } else {
-                while (w > 0 && s_empty[w - 1] == 0xFFFFFFFFu) --w;
-                start = w == 0 ? 0 : (w - 1) * 32 + 32 - __clz((int)~s_empty[w - 1]);
+        const int lastw = (H - 1) >> 5, r0 = s_r0;
+        for (int base = 0; base < Hp; base += 256) {
+            const int i = base + tid;
+            int vd = 0;
+            if (i < H) {
+                int up = BIG, dn = BIG;  // distance to the nearest row with a source at or above / at or below row i
+                {
+                    int w = i >> 5;
+                    u32 m = ~s_empty[w] & ((2u << (i & 31)) - 1u);
+                    while (!m && w > 0) m = ~s_empty[--w];
+                    if (m) up = i - (w * 32 + 31 - __clz((int)m));
+                }
+                {
+                    int w = i >> 5;
+                    u32 m = ~s_empty[w] & ~((1u << (i & 31)) - 1u);
+                    while (!m && w < lastw) m = ~s_empty[++w];
+                    if (m) dn = w * 32 + __ffs((int)m) - 1 - i;
+                }
+                vd = min(up, dn);
+                dlb = max(dlb, vd);
             }
-            const int k = i - start + 1;
-            const bool top = start == 0, bottom = i + 1 >= H;
-            dlb = max(dlb, (top && bottom) ? BIG : (top || bottom) ? k : (k + 1) / 2);
+            const u64 f16 = __ballot(i < H && i >= r0 && vd > PM16), f32 = __ballot(i < H && i >= r0 && vd > PM32);
+            if (lane == 0 && i < Hp) {
+                s_far[0][i >> 5] = (u32)f16;
+                s_far[0][(i >> 5) + 1] = (u32)(f16 >> 32);
+                s_far[1][i >> 5] = (u32)f32;
+                s_far[1][(i >> 5) + 1] = (u32)(f32 >> 32);
+                if (f16) atomicAdd(&s_nfar[0], __popcll(f16));
+                if (f32) atomicAdd(&s_nfar[1], __popcll(f32));
+            }
         }
-        if (dlb) atomicMax(&s_dlb, dlb);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) dlb = max(dlb, __shfl_xor(dlb, o));
+        if (lane == 0 && dlb) atomicMax(&s_dlb, dlb);
     }
     __syncthreads();
     const int misaligned = s_mis;
+    const int r0 = s_r0;
+    const bool sky_ok = premark && r0 >= SKY_MIN && r0 < H;  // rows [0, r0) can be k_sky's
+    if (tid == 0) {
+        // Which kernel family takes the frame -- a speed heuristic, never a correctness condition (the window kernels hand on
+        // every row in which they meet a pixel they cannot decide).  With source density p the chance that a pixel has no
+        // source within L1 distance R is about (1-p)^(2 R^2 + 2 R + 1); if the frame is expected to hold such pixels all
+        // over (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), a window kernel with halo R would do its work for nothing.
+        // Runs of source-free rows do not say no (l1_cv): the density is judged on the rows that are left to the window.
+        // Without the row flags (a depth epilogue: a handed-on row costs the whole frame there, k_fused's kept depths being
+        // cropped / floored already; the forced paths of the tests) the old rule stays: a run of source-free rows that forces a
+        // distance above R sends the frame to the any-distance kernels.  The l2 window kernel counts its far pixels itself.
+        // route: halo 16 if it fits, else halo 32 (three times the work per pixel, still cheaper than the any-distance
+        // kernels at a few percent density), else the any-distance kernels.
+        auto fits = [&](int R, int nfar) {
+            const long long ball = 2 * R * R + 2 * R + 1;
+            if (l2) return (long long)run_s * ball >= 14ll * H * W;
+            if (!premark) return (long long)run_s * ball >= 14ll * H * W && s_dlb <= R;
+            const int rest = H - (sky_ok ? r0 : 0) - nfar;
+            return rest > 0 && (long long)run_s * ball >= 14ll * rest * W;
+        };
+        // l2, a handful of sources (the NYU sampling patterns): ROUTE_POINTS -- every 32 x 32 tile looks at the sources that can
+        // own one of its pixels, found by distance from the tile's centre (l2pts_tile); the blocks of k_l2win's launch
+        // write the list of sources
+        const bool points = l2 && !force_general && run_s > 0 && run_s <= (u32)L2_PTS_MAX;
+        s_route = force_general ? 0 : points ? ROUTE_POINTS : fits(16, s_nfar[0]) ? 16 : fits(32, s_nfar[1]) ? 32 : 0;
+    }
+    __syncthreads();
+    const int r = s_route;
+    const bool flags = !l2 && premark && r >= 0;  // this frame's rows carry flags
+    // a frame that goes to the any-distance kernels whole gains from k_sky only what a deep sky saves them
+    const bool sky = sky_ok && (r > 0 || r0 >= SKY_MIN_GENERAL);
+    u32 *far = s_far[r == 32 ? 1 : 0];
+    if (flags && r > 0) {
+        // a tile row of the window kernel that is left with only a few rows is not worth its windows: all of it goes to the
+        // any-distance kernels.  One thread per tile row, whole words at a time.
+        const int TH = r == 16 ? th16 : th32;
+        auto bits = [&](int a, int e, int w) {  // the rows [a, e) as bits of word w
+            const int lo = max(a - 32 * w, 0), hi = min(e - 32 * w, 32);
+            return hi <= lo ? 0u : (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+        };
+        for (int t = tid; t * TH < H; t += 256) {
+            const int a = max(t * TH, sky ? r0 : 0), e = min(H, (t + 1) * TH);  // its rows below the sky
+            int keep = 0;
+            for (int w = a >> 5; w <= (e - 1) >> 5 && a < e; ++w) keep += __popc(~far[w] & bits(a, e, w));
+            if (keep && 4 * keep <= min(H, (t + 1) * TH) - t * TH)
+                for (int w = a >> 5; w <= (e - 1) >> 5; ++w) atomicOr(&far[w], bits(a, e, w));
+        }
+    }
+    __syncthreads();
+    // per row: l1_cv: 0 = the window kernel's, 1 = the any-distance kernels' (pre-marked here, or set by k_fused when it meets
+    // a pixel farther than its halo), 2 = k_sky's; l2: far pixels k_l2win counted
+    bool one = false;
+    for (int i = tid; i < H; i += 256) {
+        u32 f = 0u;
+        if (flags) f = (sky && i < r0) ? 2u : r == 0 ? (sky ? 1u : 0u) : (far[i >> 5] >> (i & 31)) & 1u;
+        one |= f == 1u;
+        rowfar[(size_t)b * H + i] = f;
+    }
+    const bool any1 = __syncthreads_or(one);
     if (tid == 0) {
         finfo[b * FI_STRIDE + FI_NSRC] = (int)run_s;
         finfo[b * FI_STRIDE + FI_NVAL] = (int)run_v;
         finfo[b * FI_STRIDE + FI_MISALIGNED] = misaligned;
         finfo[b * FI_STRIDE + FI_DLB] = s_dlb;
         finfo[b * FI_STRIDE + FI_NUNRES] = 0;
-        // Which kernel family takes the frame -- a speed heuristic, never a correctness condition (the window kernels hand on
-        // every row in which they meet a pixel they cannot decide).  With source density p the chance that a pixel has no
-        // source within L1 distance R is about (1-p)^(2 R^2 + 2 R + 1); if the frame is expected to hold such pixels all
-        // over (N (1-p)^ball > ~1, i.e. p * ball < ln N ~ 14), a window kernel with halo R would do its work for nothing.
-        // A run of source-free rows that forces a distance above R (real LiDAR frames: the empty sky) also says no for the
-        // l1 window kernel: only those rows would be redone, but its level-by-level expansion costs the more the farther
-        // apart the sources of the other rows are (scan lines: 91 us instead of 66 at the same density) -- measured slower
-        // than the any-distance kernels on the whole frame.  The l2 window kernel does not care.
-        // route: halo 16 if it fits, else halo 32 (three times the work per pixel, still cheaper than the any-distance
-        // kernels at a few percent density), else the any-distance kernels.
-        auto fits = [&](int R) { return (long long)run_s * (2 * R * R + 2 * R + 1) >= 14ll * H * W && (l2 || s_dlb <= R); };
-        // l2, a handful of sources (the NYU sampling patterns): ROUTE_POINTS -- every 32 x 32 tile looks at the sources that can
-        // own one of its pixels, found by distance from the tile's centre (l2pts_tile); the blocks of k_l2win's launch
-        // write the list of sources
-        const bool points = l2 && !force_general && run_s > 0 && run_s <= (u32)L2_PTS_MAX;
-        const int r = force_general ? 0 : points ? ROUTE_POINTS : fits(16) ? 16 : fits(32) ? 32 : 0;
-        route[b] = r;
+        finfo[b * FI_STRIDE + FI_SKY] = (flags && sky) ? r0 : 0;
+        const bool marked = flags && r > 0 && (sky || any1);
+        route[b] = marked ? (r | ROUTE_PREMARK) : r;
         negflag[b] = 0;  // k_mask_o's "this frame holds a negative value": consumed before this kernel, reset for the next pass
         const bool general = r == 0;
-        // 2: the any-distance kernels take the whole frame; k_fused sets 1 ("the rows marked in rowflag") when it meets a pixel
-        // farther than its halo, k_l2win when it hands a row of far pixels on
-        fflag2[b] = general ? 2 : 0;
-        frame_status[b] = (general || points) ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
+        // 2: the any-distance kernels take the whole frame; 1: the rows flagged 1 (pre-marked here, or by k_fused, or (l2) by
+        // k_l2win when it hands a row of far pixels on); 0: nothing for them
+        fflag2[b] = general ? ((flags && sky) ? 1 : 2) : (flags && any1) ? 1 : 0;
+        frame_status[b] = (general || r == ROUTE_POINTS || marked) ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
     }
-    // per row: l1_cv: "k_fused left a pixel of this row undecided"; l2: far pixels k_l2win counted
-    for (int i = tid; i < H; i += 256) rowfar[(size_t)b * H + i] = 0u;
     if (misaligned) {
         // rare path: scatter x at value pixels into the compacted value list
         const float *xf = x + (size_t)b * H * W;

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
     if (!ff) return;  // block-uniform
     if (ff == 1) {    // only near a row k_fused could not finish
         const int rr = i - R_MARGIN + lane;
-        if (!__any(lane <= 2 * R_MARGIN && rr >= 0 && rr < H && rowflag[(size_t)b * H + rr] != 0u)) return;
+        if (!__any(lane <= 2 * R_MARGIN && rr >= 0 && rr < H && rowflag[(size_t)b * H + rr] == 1u)) return;
     }
     const int band = i >> 5, r = i & 31;
     const int idx0 = (wv * 64 + lane) * PPL;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     u32 coremask = 0xFFFFFFFFu;
     if (ff == 1) {
         const int l = tid & 63;
-        coremask = (u32)__ballot(l < Q_TH && r0 + l < H && rowflag[(size_t)b * H + min(r0 + l, H - 1)] != 0u);
+        coremask = (u32)__ballot(l < Q_TH && r0 + l < H && rowflag[(size_t)b * H + min(r0 + l, H - 1)] == 1u);
         if (!coremask) return;  // block-uniform: every wave computes the same mask
     }
     const int wpr = Wp >> 2;  // 32-pixel words per plane row
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256) void k_tiesx(const u8 *__restrict__ unres, int
         for (int step = 0; step < H * W; ++step) {  // every step ends on a pixel nearer to the sources
             const u32 pi = p / (u32)W, pj = p - pi * (u32)W;
             // a row that was not redone holds k_fused's finished pixels (and no "unresolved" bits of this pass)
-            const bool redone = ff != 1 || rowflag[rowb + pi] != 0u;
+            const bool redone = ff != 1 || rowflag[rowb + pi] == 1u;
             const u32 open = (unres[(rowb + pi) * Wp + (pj >> 3)] >> (pj & 7u)) & 1u;
             const u32 nx = xptr[fo + p];  // meaningful only if open
             if (!redone || !open) break;

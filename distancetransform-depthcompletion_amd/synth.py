@@ -62,6 +62,10 @@ CONFIGS = {
     "kitti_b32_scanline": dict(gen="kitti_scanline", B=32, H=352, W=1216, kwargs=dict(seed=0)),
     "nyu_b64": dict(gen="nyu_pattern", B=64, H=480, W=640, kwargs=dict(n=200, seed=0)),
     "synth2048_b16": dict(gen="iid", B=16, H=2048, W=2048, kwargs=dict(p=0.01, seed=2)),
+    # the reference's other real shapes: the KITTI frame as eval_NYU.py:157 feeds it (rows 96: of 352 x 1216 -> 256 x 1216) and
+    # NYU after the loader's resize to 240 x 320 (data_read.py:350-352) with the sampling pattern of data_read.py:360-364
+    "kitti_crop256": dict(gen="kitti_scanline", B=4, H=256, W=1216, kwargs=dict(seed=3, hw=(256, 1216), empty_rows=4)),
+    "nyu_240x320": dict(gen="nyu_pattern", B=4, H=240, W=320, kwargs=dict(n=200, seed=4, hw=(240, 320))),
 }
 
 

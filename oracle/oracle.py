@@ -163,7 +163,8 @@ def outlier_removal(lidar):
     OpenCV again, PARITY UNPINNED): default border BORDER_REFLECT_101; for the float32 frame OpenCV
     accumulates in float32 over the non-zero kernel taps in kernel row-major order; the valid-pixel
     count is computed on a float64 image (np.float), so it is exact; mean, difference and the > 1.0 test
-    are float64 by numpy promotion; the result is the frame with the flagged pixels zeroed, float32."""
+    are float64 by numpy promotion; the result is the frame times (1 - flag): flagged pixels become a zero that
+    keeps the pixel's sign, float32."""
     x = np.squeeze(np.asarray(lidar)).astype(np.float32)
     H, W = x.shape
     pad = np.pad(x, 3, mode="reflect")  # numpy 'reflect' == BORDER_REFLECT_101
@@ -176,8 +177,10 @@ def outlier_removal(lidar):
                 acc = (acc + win).astype(np.float32)  # sequential float32 accumulation, row-major taps
                 cnt += win > 0.1
     mean = acc / (cnt + 0.00001)  # float32 / float64 -> float64
-    outlier = (x - mean) > 1.0
-    return np.where(outlier, np.float32(0), x).astype(np.float32)
+    outlier = ((x - mean) > 1.0).astype(np.float64)  # (...).astype(np.float) in the reference
+    # data_read.py:128 multiplies: a removed NEGATIVE pixel comes out as -0.0, not +0.0 (float32 * float64 -> float64 -> float32)
+    with np.errstate(invalid="ignore"):
+        return (x * (1 - outlier)).astype(np.float32)
 
 
 def fill_batch(x, src_thr=0.1, val_thr=0.1, metric="l1_cv"):

@@ -129,7 +129,8 @@ def main():
 
     # full-size frames: (generator, seed) -> sha256 of the oracle outputs
     dig = {}
-    for cfg, B in [("kitti_b32", 2), ("kitti_b32_scanline", 1), ("nyu_b64", 2), ("synth2048_b16", 1)]:
+    for cfg, B in [("kitti_b32", 2), ("kitti_b32_scanline", 1), ("nyu_b64", 2), ("synth2048_b16", 1), ("kitti_crop256", 2),
+                   ("nyu_240x320", 2)]:
         x = synth.make(cfg, B=B)
         depth, dt, lbl, status = O.fill_batch(x)
         for b in range(B):

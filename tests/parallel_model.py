@@ -344,3 +344,85 @@ def l2_envelope(src):
             d2[i, j] = g2 + (j - k) ** 2
             near[i, j] = sr * W + k
     return d2, near, evals / (H * W)
+
+
+def sky_rows(dt, lbl):
+    """k_sky: the rows above the first source row r0, from rows r0 and r0 + 1 of a finished (dt, lbl) pair alone.
+    Returns (dt, lbl) with rows [0, r0) recomputed (the input's are ignored), or the input unchanged when the frame has no
+    sky (a source in row 0, or no source at all).  The statement of dtfill_sky.hpp: a step code per column for the rows
+    up to r0 - 2, the five leading backward taps on the real distances for row r0 - 1."""
+    H, W = dt.shape
+    rows = np.flatnonzero((dt == 0).any(axis=1))
+    if rows.size == 0 or rows[0] == 0:
+        return dt, lbl
+    r0 = int(rows[0])
+    f = dt[r0].astype(np.int64)
+    two = r0 + 1 < H
+    g = dt[r0 + 1].astype(np.int64) if two else None
+    dt, lbl = dt.copy(), lbl.copy()
+    base = np.concatenate([lbl[r0], lbl[r0 + 1] if two else lbl[r0]])
+    j = np.arange(W)
+    key = {r0: j.copy()}
+    # row r0 - 1
+    D = f + 1
+    k = j.copy()
+    taken = np.zeros(W, bool)
+
+    def offer(cond, val):
+        nonlocal k, taken
+        sel = cond & ~taken
+        k = np.where(sel, val, k)
+        taken |= cond
+
+    pad = lambda a: np.concatenate([np.full(2, BIG), a, np.full(2, BIG)])
+    sh = lambda a, s: pad(a)[2 + s : 2 + s + W]  # a[j + s], BIG outside the row
+    if two:
+        offer(sh(g, 1) + 3 == D, W + j + 1)
+        offer(sh(g, -1) + 3 == D, W + j - 1)
+    offer(sh(f, 2) + 3 == D, j + 2)
+    offer(sh(f, 1) + 2 == D, j + 1)
+    key[r0 - 1] = k
+    step = np.where(sh(f, 1) + 1 == f, 1, np.where(sh(f, -1) + 1 == f, 2, 0))
+    for i in range(r0 - 2, -1, -1):
+        k2, k1 = key[i + 2], key[i + 1]
+        key[i] = np.where(step == 1, np.concatenate([k2, [0]])[1 : W + 1], np.where(step == 2, np.concatenate([[0], k2])[:W], k1))
+    for i in range(r0):
+        dt[i] = (f + (r0 - i)).astype(dt.dtype)
+        lbl[i] = base[key[i]]
+    return dt, lbl
+
+
+def sky_rows_closed_form(dt, lbl):
+    """k_sky as the kernel computes it: no row-by-row propagation.  The step code of a column is the same in every row up to
+    r0 - 2, a (+2,+1) column is followed by (+2,+1) columns up to a (+1,0) column (mirror image for (+2,-1)), and a (+1,0)
+    column repeats row r0 - 1 all the way up.  So pixel (i, j) takes t = min(run length of its column, floor((r0 - i) / 2))
+    hops of (+2, +-1) and lands in row i + 2 t: in row r0 on the base pixel itself, in any row above on what row r0 - 1 holds
+    in that column."""
+    H, W = dt.shape
+    rows = np.flatnonzero((dt == 0).any(axis=1))
+    if rows.size == 0 or rows[0] == 0:
+        return dt, lbl
+    r0 = int(rows[0])
+    f = dt[r0].astype(np.int64)
+    first_dt, first_lbl = sky_rows(dt, lbl)  # row r0 - 1 by the five taps (the model above), the rest is replaced below
+    first = first_lbl[r0 - 1]
+    pad = lambda a: np.concatenate([np.full(2, BIG), a, np.full(2, BIG)])
+    sh = lambda a, s: pad(a)[2 + s : 2 + s + W]
+    A = sh(f, 1) + 1 == f
+    Bm = ~A & (sh(f, -1) + 1 == f)
+    run = np.zeros(W, np.int64)  # consecutive A columns from j rightwards / B columns leftwards
+    for j in range(W - 1, -1, -1):
+        if A[j]:
+            run[j] = 1 + (run[j + 1] if A[j + 1] else 0)
+    for j in range(W):
+        if Bm[j]:
+            run[j] = 1 + (run[j - 1] if Bm[j - 1] else 0)
+    direction = np.where(A, 1, np.where(Bm, -1, 0))
+    out_dt, out_lbl = dt.copy(), lbl.copy()
+    j = np.arange(W)
+    for i in range(r0):
+        t = np.zeros(W, np.int64) if i == r0 - 1 else np.minimum(run, (r0 - i) // 2)
+        col = j + direction * t
+        out_lbl[i] = np.where(i + 2 * t == r0, lbl[r0][col], first[col])
+        out_dt[i] = (f + (r0 - i)).astype(dt.dtype)
+    return out_dt, out_lbl

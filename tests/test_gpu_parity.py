@@ -7,10 +7,11 @@ import os
 import numpy as np
 import pytest
 
-from helpers import digest, load_cases
+from helpers import digest, labels_from_nearest, load_cases, load_l2_cases
 
 pytestmark = pytest.mark.gpu
 CASES, DIGESTS = load_cases()
+L2_CASES, L2_DIGESTS = load_l2_cases()
 
 
 PATHS = ("auto", "general")  # every comparison runs through the fused+fallback pass AND the general kernels alone
@@ -291,6 +292,47 @@ def test_l2_metric_vs_oracle(pkg, oracle):
         assert np.array_equal(got["depth"][ok], depth[ok], equal_nan=True)
 
 
+def _run_l2(pkg, x, path="auto"):
+    import torch
+
+    op2 = pkg.device.DtFill(device="cuda:0", metric="l2")
+    res = op2.run(torch.from_numpy(np.ascontiguousarray(x, np.float32)).to("cuda:0"), path=path)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in res.items()}
+
+
+@pytest.mark.parametrize("path", ("auto", "general"))
+def test_l2_scipy_pinned_cases(pkg, path):
+    """The l2 mode against fixtures written from scipy.ndimage.distance_transform_edt (tests/golden/make_golden_l2.py; north_star:
+    index map bit-exact, distance within 1e-5 relative): squared distances are scipy's, the index is the canonical one
+    (smallest raster index among the equidistant sources, pinned by brute force when the fixtures were made).  Both kernel
+    families (window + far list; column distances + envelope search / tile search)."""
+    for name, c in L2_CASES.items():
+        got = _run_l2(pkg, c["x"][None], path)
+        if (c["near"] < 0).all():
+            assert np.isinf(got["dt"]).all() and (got["index"] == 0).all(), name
+            continue
+        assert np.array_equal(got["index"][0], labels_from_nearest(c["x"], c["near"])), name
+        want = np.sqrt(c["d2"].astype(np.float64))
+        assert np.allclose(got["dt"][0], want, rtol=1e-5, atol=0), name  # tolerance of BASELINE.json's north_star
+        src = c["x"] >= 0.9
+        assert np.array_equal(got["depth"][0], c["x"].ravel()[c["near"].ravel()].reshape(c["x"].shape)) or not src.any(), name
+
+
+@pytest.mark.parametrize("cfg", sorted(L2_DIGESTS))
+def test_l2_full_size_digests_from_scipy(pkg, cfg):
+    """BASELINE.json's shapes (and the reference's two other real shapes) in the l2 mode: squared distances and canonical
+    labels hashed against the digests the scipy-checked generator committed."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    d = L2_DIGESTS[cfg]
+    x = synth.make(cfg, B=d["B"])
+    assert digest(x) == d["x"]
+    got = _run_l2(pkg, x)
+    assert digest(got["index"]) == d["lbl"]
+    assert digest(got["depth"]) == d["depth"]
+    assert digest(np.round(got["dt"].astype(np.float64) ** 2).astype(np.int32)) == d["d2"]
+
+
 def test_l2_full_size_properties(pkg, oracle):
     """KITTI-size batch in l2 mode: the index is a true Euclidean-nearest source (checked against
     the exact transform of a few frames) and one full frame equals the oracle."""
@@ -532,7 +574,7 @@ def test_outlier_removal_vs_oracle(pkg, oracle):
         got = pkg.outlier_removal(x[None, :, :, None])
         want = oracle.outlier_removal(x)
         assert got.dtype == np.float32 and got.shape == (H, W)
-        assert np.array_equal(got, want)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))  # bit patterns: the sign of a removed zero counts
         assert (want != x).any() or H < 8
 
 
@@ -557,7 +599,9 @@ def test_outlier_removal_special_values(pkg, oracle):
     for name, x in cases.items():
         got = pkg.outlier_removal(x[None, :, :, None])
         want = oracle.outlier_removal(x)
-        assert np.array_equal(got, want, equal_nan=True), name
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name  # bit patterns (NaN payloads, -0.0 of a removed negative)
+    removed_neg = (cases["negative"] < 0) & (oracle.outlier_removal(cases["negative"]) == 0)
+    assert not removed_neg.any() or np.signbit(oracle.outlier_removal(cases["negative"])[removed_neg]).all()
     assert (cases["small values next to a negative"] != oracle.outlier_removal(cases["small values next to a negative"])).any()
 
 
@@ -803,6 +847,47 @@ def test_stray_points_in_the_sky(gpu_op, oracle):
     x = np.stack(frames)
     assert_equal_to_oracle(oracle, gpu_op, x)
     assert run(gpu_op, x, path="auto")["general"].all()
+
+
+def test_rows_marked_up_front_for_the_any_distance_kernels(gpu_op, oracle, pkg):
+    """LiDAR-like frames (empty sky, ring rows): k_frame hands the rows that are too far from every row with a source to the
+    any-distance kernels before the window kernel runs, and the window kernel takes the rest of the frame (its tiles shrink to
+    their unmarked rows; a tile row left with a few rows is marked whole).  Sky heights around the marking distances and the
+    tile heights, bands at the bottom and in the middle, ring spacings, both halos, shapes that do not divide into tiles,
+    stray sources inside the sky, differing thresholds -- all bit-exact, and such frames report the general-path bit."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    rng = np.random.default_rng(91)
+    x = synth.make("kitti_b32_scanline", B=3)
+    assert_equal_to_oracle(oracle, gpu_op, x)
+    assert run(gpu_op, x)["general"].all()
+
+    def rings(H, W, top, step, p, bottom=0):
+        a = np.where(rng.random((H, W)) < p, rng.uniform(1.0, 80.0, (H, W)), 0.0).astype(np.float32)
+        keep = np.zeros(H, bool)
+        keep[top:H - bottom:step] = True
+        a[~keep] = 0
+        return a
+
+    for H, W in ((352, 1216), (417, 1000), (200, 640)):
+        frames = []
+        for top in (9, 17, 40, 87, 88, 100, H - 12):
+            frames.append(rings(H, W, top, 4, 0.25))
+        frames.append(rings(H, W, 60, 2, 0.15, bottom=70))   # sky on top and an empty band at the bottom
+        frames.append(rings(H, W, 30, 8, 0.5))               # rings 8 apart
+        frames.append(rings(H, W, 50, 12, 0.6))              # 12 apart: the rows between two rings are near the marking distance
+        a = rings(H, W, 0, 1, 0.05); a[90:150] = 0; frames.append(a)     # a band in the middle of an iid frame
+        a = rings(H, W, 0, 1, 0.012); a[:70] = 0; frames.append(a)       # thin: halo 32, its own marking distance
+        a = rings(H, W, 0, 1, 0.012); a[120:175] = 0; frames.append(a)
+        a = rings(H, W, 100, 4, 0.25)                                    # stray sources in the sky, some on a diagonal
+        for _ in range(8):
+            i, j = int(rng.integers(0, 95)), int(rng.integers(0, W - 40))
+            a[i, j] = 3.0
+            if rng.random() < 0.5:
+                a[i + 5, j + 5] = 4.0
+        frames.append(a)
+        x = np.stack(frames)
+        assert_equal_to_oracle(oracle, gpu_op, x)
+        assert_equal_to_oracle(oracle, gpu_op, x[:4], st=0.1, vt=30.0)  # value list differs from the source list
 
 
 # ------------------------------------------------------------------------------------------------

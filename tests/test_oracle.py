@@ -155,3 +155,44 @@ def test_real_cv2_if_present(oracle):
         dt, lbl = cv2.distanceTransformWithLabels(mask, cv2.DIST_L1, 5, labelType=cv2.DIST_LABEL_PIXEL)
         d0, l0 = oracle.cv_distance_transform_with_labels(mask)
         assert np.array_equal(dt, d0) and np.array_equal(lbl, l0)
+
+
+def test_oracle_sanitized():
+    """the CPU restatement under AddressSanitizer + UBSan (host build only -- the GPU pool has no sanitizer
+    for device code).  oracle/asan_main.c drives every entry point over awkward shapes; any report fails the run."""
+    import shutil
+    import subprocess
+
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    if shutil.which("gcc") is None and shutil.which("cc") is None:
+        pytest.skip("no C compiler")
+    subprocess.check_call(["make", "-s", "-C", here, "oracle_asan"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([os.path.join(here, "oracle_asan")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "oracle_asan ok" in r.stdout and "runtime error" not in r.stderr and "ERROR" not in r.stderr, r.stderr[-2000:]
+
+
+def test_l2_oracle_against_the_scipy_pinned_fixtures(oracle, pkg):
+    """tests/golden/l2_cases.npz was written from scipy.ndimage.distance_transform_edt (squared distances exact; canonical
+    tie by brute force): the l2 oracle must reproduce it, and the full-size digests of the two KITTI shapes."""
+    import importlib
+
+    from helpers import digest, labels_from_nearest, load_l2_cases
+
+    cases, digests = load_l2_cases()
+    for name, c in cases.items():
+        src = ~((np.float32(1.0) - c["x"]) > np.float32(0.1))
+        d2, near = oracle.edt_l2((~src).astype(np.uint8))
+        if src.any():
+            assert np.array_equal(d2, c["d2"]) and np.array_equal(near, c["near"]), name
+        depth, dt, idx, status = oracle.fill_batch(c["x"][None], metric="l2")
+        assert np.array_equal(idx[0], labels_from_nearest(c["x"], c["near"])), name
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    for cfg in ("kitti_b32_scanline", "nyu_240x320"):
+        d = digests[cfg]
+        x = synth.make(cfg, B=d["B"])
+        assert digest(x) == d["x"]
+        depth, dt, idx, status = oracle.fill_batch(x, metric="l2")
+        assert digest(idx) == d["lbl"] and digest(depth) == d["depth"]
+        assert digest(np.round(dt.astype(np.float64) ** 2).astype(np.int32)) == d["d2"]

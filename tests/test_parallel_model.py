@@ -124,3 +124,38 @@ def test_l2_envelope_search_matches_the_exact_transform(oracle):
         d2, near, evals = PM.l2_envelope(src)
         assert np.array_equal(d2, d2o) and np.array_equal(near, nearo)
         assert evals <= 2 * np.log2(max(W, 2)) + 4
+
+
+def test_sky_rows_follow_from_the_two_rows_beneath(oracle):
+    """k_sky's formulation: the rows above the first source row, recomputed from rows r0 and r0 + 1 of the oracle's own result,
+    equal the oracle's.  Ring rows under a sky of several heights, stray first rows, a single source row at the very
+    bottom (no row r0 + 1), widths 1 and 2, diagonal partners right under the sky (ties along lines)."""
+    import parallel_model as P
+
+    rng = np.random.default_rng(7)
+    n = 0
+    for trial in range(300):
+        H, W = int(rng.integers(2, 70)), int(rng.integers(1, 90))
+        top = int(rng.integers(1, H))
+        x = np.where(rng.random((H, W)) < rng.choice([0.02, 0.1, 0.3, 0.7]), rng.uniform(1, 80, (H, W)), 0).astype(np.float32)
+        x[:top] = 0
+        if trial % 3 == 0:
+            keep = np.zeros(H, bool)
+            keep[top::int(rng.integers(2, 6))] = True
+            x[~keep] = 0
+        if trial % 5 == 0 and top + 2 < H and W > 6:
+            x[top] = 0
+            x[top, 2], x[top + 2, 4] = 3.0, 4.0
+        if not (x >= 0.9).any():
+            x[H - 1, W // 2] = 5.0
+        dt, lbl = oracle.nearest_point(x) if min(H, W) > 1 else oracle.fill_batch(x[None])[1:3]
+        dt, lbl = np.asarray(dt).reshape(H, W), np.asarray(lbl).reshape(H, W)
+        junk_dt, junk_lbl = dt.copy(), lbl.copy()
+        r0 = int(np.flatnonzero((dt == 0).any(axis=1))[0])
+        junk_dt[:r0], junk_lbl[:r0] = -1, -7  # the model must not look at the sky rows it is given
+        d2, l2 = P.sky_rows(junk_dt, junk_lbl)
+        assert np.array_equal(d2, dt) and np.array_equal(l2, lbl), (trial, H, W, r0)
+        d3, l3 = P.sky_rows_closed_form(junk_dt, junk_lbl)  # what the kernel evaluates: a hop count per pixel, no row loop
+        assert np.array_equal(d3, dt) and np.array_equal(l3, lbl), (trial, H, W, r0)
+        n += r0 > 0
+    assert n > 200
