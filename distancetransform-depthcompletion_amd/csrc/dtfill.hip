@@ -65,6 +65,7 @@ namespace {
 #include "dtfill_fused.hpp"
 #include "dtfill_rows.hpp"
 #include "dtfill_sky.hpp"
+#include "dtfill_pts.hpp"
 #include "dtfill_l2.hpp"
 #include "dtfill_outlier.hpp"
 #include "dtfill_gmc.hpp"
@@ -91,6 +92,7 @@ struct Carve {
     int32_t *labelmap;   // k_labels: at every source pixel, its label (1 + raster rank among the frame's sources)
     int *finfo, *fflag2, *route, *status, *negflag;
     float *vlist;
+    PtsSrc *ptslist;     // k_frame -> k_pts: the sources of a frame that has a handful (l1_cv, ROUTE_POINTS)
     size_t total;
 };
 
@@ -133,6 +135,7 @@ Carve carve(void *ws, int B, int H, int W) {
     c.plane_bytes = align256(NW * 8);
     c.planes = (u8 *)take(PL_N * c.plane_bytes);
     c.vlist = (float *)take(N * 4);
+    c.ptslist = (PtsSrc *)take((size_t)B * L2_PTS_MAX * sizeof(PtsSrc));
     c.total = off;
     return c;
 }
@@ -142,8 +145,8 @@ bool shape_ok(int B, int H, int W) {
            (long long)B * H * W < (1ll << 31);  // B is a grid dimension; pixel indices are 32-bit
 }
 
-constexpr int NK_L1 = 8;
-const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_colT", "k_rows", "k_fin", "k_tiesx", "k_sky"};
+constexpr int NK_L1 = 9;
+const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_pts", "k_colT", "k_rows", "k_fin", "k_tiesx", "k_sky"};
 
 // k_mask4 when the rows can be read 16 bytes at a time, k_mask otherwise (same outputs); with DTFILL_FLAG_OUTLIER_REMOVAL the
 // predicates see outlier_removal(x) (k_mask_o, then its exhaustive variant for the frames that hold a negative value)
@@ -207,8 +210,9 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     // k_sky takes the distances of its two base rows from the distance map: without one from the caller, the scratch frame
     float *const out_dt_caller = out_dt;
     if (rowflags && !out_dt) out_dt = c.dscratch;
-    k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v, c.finfo, c.vlist,
-                               c.fflag2, c.route, status, (general_only ? 1 : 0) | (rowflags ? 4 : 0), c.negflag, c.rowfar, t16.TH, t32.TH);
+    k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.srcbits, c.wpre_s, c.ptslist, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
+                               c.finfo, c.vlist, c.fflag2, c.route, status, (general_only ? 1 : 0) | (rowflags ? 4 | 8 : 0), c.negflag, c.rowfar,
+                               t16.TH, t32.TH);
     mark();
     if (!general_only) {
         // dense frames: the window kernel, halo 16 or 32 per frame (k_frame's route).  It hands rows on (fflag2, rowflag) when a
@@ -228,6 +232,14 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     if (!fused_only) {
         // every other frame: argmin scans, any distance (dtfill_rows.hpp)
         const int nb = c.nb;
+        if (rowflags) {
+            // frames with a handful of sources (k_frame: ROUTE_POINTS), from the source list to the outputs; k_tiesx finishes
+            // the chains that leave a tile
+            const int ptx = (W + Q_TW - 1) / Q_TW, pty = (H + Q_TH - 1) / Q_TH;
+            k_pts<<<dim3(ptx * pty, B), Q_NT, 0, st>>>(x, c.ptslist, c.route, H, W, Wd * 8, ptx, c.vlist, out_depth, out_dt, out_index, status, c.finfo,
+                                                       c.xlist, c.xptr, c.planes + PL_UNRES * c.plane_bytes);
+        }
+        mark();
         const int cw = min(16, max(2, (nb + 3) / 4));  // two iterations of two bands per wave: fewer, longer waves fit the CUs in one round
         k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, colT_lds(nb), st>>>(
             c.srcbits, c.fflag2, H, W, Wd, nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s, (out_depth || out_index) ? c.labelmap : nullptr);
@@ -273,7 +285,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
             mark();
         }
     } else {
-        for (int t = 0; t < 4; ++t) mark();
+        for (int t = 0; t < 5; ++t) mark();
     }
     if (rowflags) {
         const size_t lds = sky_lds(sky_span_max(H, W));
@@ -304,7 +316,7 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     mark();
     launch_mask(x, B, H, W, Wd, src_thr, val_thr, c, flags, st);
     mark();
-    k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
+    k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.srcbits, c.wpre_s, c.ptslist, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
                                c.finfo, c.vlist, c.fflag2, c.route, status, (general_only ? 1 : 0) | 2, c.negflag, c.rowfar, 0, 0);
     mark();
     // dense frames (k_frame's route 16 / 32): windows of 15 x 15 / 31 x 31 around every pixel, the few pixels with no source

@@ -13,6 +13,11 @@ constexpr int FI_SKY = 5;     // l1_cv: rows [0, FI_SKY) hold no source and lie 
 constexpr int FI_STRIDE = 8;
 constexpr int ROUTE_POINTS = -1;  // route[b]: l2, at most L2_PTS_MAX sources in the frame (k_l2pts)
 constexpr int L2_PTS_MAX = 512;
+struct PtsSrc {  // one source of such a frame's list (k_frame writes it in raster order: index = label - 1; k_pts reads it)
+    u32 rc;      // row << 16 | column
+    float v;     // its depth
+};
+constexpr int PTS_BAND_MAX = 96;  // l1_cv: ... and at most this many in any band of 32 rows
 // route[b] | ROUTE_PREMARK (l1_cv): k_frame marked rows of the frame for the any-distance kernels up front (rows farther than
 // PM16 / PM32 from every row that holds a source: the window kernel with halo 16 / 32 could not decide them, or only by running
 // its level loop to the end for a handful of their pixels)

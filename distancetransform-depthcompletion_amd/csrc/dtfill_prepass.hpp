@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void k_mask4(const float *__restrict__ x, int 
 // masks differ somewhere in the frame.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, const u64 *__restrict__ valbits,
-                                               const u16 *__restrict__ wpre_v,
+                                               const u16 *__restrict__ wpre_v, const u64 *__restrict__ srcbits,
+                                               const u16 *__restrict__ wpre_s, PtsSrc *__restrict__ ptslist,
                                                const u32 *__restrict__ rowcnt_s,
                                                const u32 *__restrict__ rowcnt_v, int H, int W, int Wd,
                                                u32 *__restrict__ rowbase_s, u32 *__restrict__ rowbase_v,
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     const bool force_general = mode & 1;  // every frame takes the any-distance kernels (tests)
     const bool l2 = mode & 2;             // l2: the window kernel's cost does not grow with the distances it meets
     const bool premark = mode & 4;        // l1_cv without a depth epilogue: rows too far from every source row are handed on up front
+    const bool pts_ok = mode & 8;         // l1_cv: a frame with a handful of sources may go to k_pts
     __shared__ u32 s_ws[4], s_wv[4];
     __shared__ int s_mis, s_dlb;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -291,12 +293,15 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     // "Row has no source" as bits in LDS (H <= 8191 -> 256 words); the rows past H count as empty.
     __shared__ u32 s_empty[256];
     __shared__ u32 s_far[2][256];  // bit i: row i >= r0 and vd(i) > PM16 / > PM32
-    __shared__ int s_nfar[2], s_r0, s_route;
+    __shared__ int s_nfar[2], s_r0, s_route, s_bandmax;
     {
         // a wave holds 64 consecutive rows: the row bits leave as two whole words per ballot, no atomics
         const int Hp = (H + 63) & ~63;
         if (tid < 2) s_nfar[tid] = 0;
-        if (tid == 0) s_r0 = H;
+        if (tid == 0) {
+            s_r0 = H;
+            s_bandmax = 0;
+        }
         for (int w = tid + (Hp >> 5); w < 256; w += 256) s_empty[w] = 0xFFFFFFFFu;
         __syncthreads();
         for (int base = 0; base < Hp; base += 256) {
@@ -313,6 +318,12 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         const int lastw = (H - 1) >> 5, r0 = s_r0;
         for (int base = 0; base < Hp; base += 256) {
             const int i = base + tid;
+            {   // sources per band of 32 rows (k_pts's tiles are that high): the largest one
+                u32 c = i < H ? cs_[i] : 0u;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) c += (u32)__shfl_xor((int)c, o);
+                if ((lane & 31) == 0 && c) atomicMax(&s_bandmax, (int)c);
+            }
             int vd = 0;
             if (i < H) {
                 int up = BIG, dn = BIG;  // distance to the nearest row with a source at or above / at or below row i
@@ -371,10 +382,48 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         // own one of its pixels, found by distance from the tile's centre (l2pts_tile); the blocks of k_l2win's launch
         // write the list of sources
         const bool points = l2 && !force_general && run_s > 0 && run_s <= (u32)L2_PTS_MAX;
-        s_route = force_general ? 0 : points ? ROUTE_POINTS : fits(16, s_nfar[0]) ? 16 : fits(32, s_nfar[1]) ? 32 : 0;
+        // l1_cv, a handful of sources and too thin for a window: k_pts (per tile, the sources whose cells reach it).  Not when they
+        // crowd into one band of rows: its tiles would look at all of them for every pixel.
+        const bool points1 = !l2 && pts_ok && run_s > 0 && run_s <= (u32)L2_PTS_MAX && s_bandmax <= PTS_BAND_MAX;
+        const int window = fits(16, s_nfar[0]) ? 16 : fits(32, s_nfar[1]) ? 32 : 0;
+        s_route = force_general ? 0 : points ? ROUTE_POINTS : window ? window : points1 ? ROUTE_POINTS : 0;
     }
     __syncthreads();
     const int r = s_route;
+    if (!l2 && r == ROUTE_POINTS) {
+        // the frame's sources in raster order (index = label - 1), for k_pts
+        PtsSrc *list = ptslist + (size_t)b * L2_PTS_MAX;
+        // a thread per row that holds a source (few do); the row's words four at a time (independent loads)
+        for (int i = tid; i < H; i += 256) {
+            if (cs_[i] == 0) continue;
+            const u64 *row = srcbits + ((size_t)b * H + i) * Wd;
+            u32 k = bs_[i];  // (this block wrote bs_ above, before a barrier)
+            for (int w0 = 0; w0 < Wd; w0 += 4) {
+                u64 sb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sb[q] = w0 + q < Wd ? row[w0 + q] : 0ull;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u64 m = sb[q];
+                    while (m) {
+                        const int j = (w0 + q) * 64 + __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        list[k++].rc = (u32)i << 16 | (u32)j;
+                    }
+                }
+            }
+        }
+    }
+    if (!l2 && r == ROUTE_POINTS) {
+        // ... and their depths, every source by a thread of its own (one round trip for all of them)
+        __syncthreads();
+        PtsSrc *list = ptslist + (size_t)b * L2_PTS_MAX;
+        const float *xf = x + (size_t)b * H * W;
+        for (int k = tid; k < (int)run_s; k += 256) {
+            const u32 rc = list[k].rc;
+            list[k].v = xf[(size_t)(rc >> 16) * W + (rc & 0xFFFFu)];
+        }
+    }
     const bool flags = !l2 && premark && r >= 0;  // this frame's rows carry flags
     // a frame that goes to the any-distance kernels whole gains from k_sky only what a deep sky saves them
     const bool sky = sky_ok && (r > 0 || r0 >= SKY_MIN_GENERAL);
@@ -419,7 +468,8 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         const bool general = r == 0;
         // 2: the any-distance kernels take the whole frame; 1: the rows flagged 1 (pre-marked here, or by k_fused, or (l2) by
         // k_l2win when it hands a row of far pixels on); 0: nothing for them
-        fflag2[b] = general ? ((flags && sky) ? 1 : 2) : (flags && any1) ? 1 : 0;
+        // 3 (l1_cv, ROUTE_POINTS): k_pts takes the frame, of the any-distance kernels only k_tiesx has something to do
+        fflag2[b] = (!l2 && r == ROUTE_POINTS) ? 3 : general ? ((flags && sky) ? 1 : 2) : (flags && any1) ? 1 : 0;
         frame_status[b] = (general || r == ROUTE_POINTS || marked) ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
     }
     if (misaligned) {

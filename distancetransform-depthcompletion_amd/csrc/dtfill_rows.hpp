@@ -52,7 +52,7 @@ __device__ __forceinline__ void colT_block(const u64 *__restrict__ srcbits, cons
                                            int32_t *__restrict__ labelmap, int wd, u16 *s_lf, u64 (*s_rowword)[64]) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
-    if (fflag && !fflag[b]) return;
+    if (fflag && (!fflag[b] || fflag[b] == 3)) return;  // 3: k_pts's frame
     const int j = wd * 64 + lane;
     const bool real = wd < Wd;  // block-uniform: word columns beyond the image only write the "no source" padding
     u16 *s_last = s_lf, *s_first = s_lf + nb * 64;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
     const int i = blockIdx.x, b = blockIdx.y;
     const int ff = fflag[b];
-    if (!ff) return;  // block-uniform
+    if (!ff || ff == 3) return;  // block-uniform (3: k_pts's frame)
     if (ff == 1) {    // only near a row k_fused could not finish
         const int rr = i - R_MARGIN + lane;
         if (!__any(lane <= 2 * R_MARGIN && rr >= 0 && rr < H && rowflag[(size_t)b * H + rr] == 1u)) return;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     __shared__ u32 s_cnt[Q_NT / 64];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int ff = fflag[b];
-    if (!ff) return;
+    if (!ff || ff == 3) return;  // 3: k_pts's frame
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * Q_TH, c0 = tx * Q_TW;
     // the tile's rows that are redone: all of them, or (ff == 1) those k_fused marked; the others keep k_fused's results

@@ -505,6 +505,60 @@ def test_l2_frames_with_a_handful_of_sources(pkg, oracle):
     assert_l2_equal_to_oracle(oracle, op2, mix)
 
 
+def test_l1_frames_with_a_handful_of_sources(gpu_op, oracle):
+    """l1_cv, at most 512 sources in a frame too thin for a window (the NYU sampling patterns): k_pts -- per tile the sources
+    whose cells reach it, pruned by dominance on the box's corners, packed-key minima per pixel, k_fin's rule for the tie
+    pixels.  512 / 513 sources (the routing boundary), clusters (more than 64 candidates per wave: the slow lists; more than
+    96 in one band of rows: back to the any-distance kernels), one source, diagonal partners (ties along lines, chains that
+    cross tiles and go to k_tiesx), regular lattices (many-way ties), frames smaller than a tile, widths that are no multiple
+    of 4 / 32, sources on the frame's edges, values that are not sources, every route in one batch, optional outputs."""
+    rng = np.random.default_rng(2718)
+
+    def pts(H, W, n, box=None, lo=0.95):
+        f = np.zeros((H, W), np.float32)
+        r0, r1, c0, c1 = box or (0, H, 0, W)
+        pos = rng.choice((r1 - r0) * (c1 - c0), n, replace=False)
+        f[r0 + pos // (c1 - c0), c0 + pos % (c1 - c0)] = rng.uniform(lo, 10, n)
+        return f
+
+    for n in (1, 2, 37, 200, 512, 513):
+        assert_equal_to_oracle(oracle, gpu_op, np.stack([pts(480, 640, n), pts(480, 640, max(1, n // 2))]))
+    assert_equal_to_oracle(oracle, gpu_op, pts(300, 700, 90, box=(100, 130, 200, 260))[None])   # 90 sources in one band, close together
+    assert_equal_to_oracle(oracle, gpu_op, pts(300, 700, 400, box=(0, 40, 0, 60))[None])       # a crowd in a corner: not k_pts's
+    assert_equal_to_oracle(oracle, gpu_op, pts(200, 333, 50, box=(150, 200, 300, 333))[None])
+    assert_equal_to_oracle(oracle, gpu_op, pts(480, 640, 300, box=(0, 480, 600, 640))[None])   # a strip on the right edge
+    x = np.zeros((4, 90, 130), np.float32)
+    x[0, 10, 10] = x[0, 50, 50] = 3.0     # every pixel of the anti-diagonal band between them is a tie
+    x[1, 0, 129] = x[1, 89, 0] = 4.0
+    x[2, ::15, ::13] = 2.0                # a lattice: three- and four-way ties
+    x[3, 0, :] = 0
+    x[3, 0, 0] = x[3, 0, 129] = x[3, 89, 0] = x[3, 89, 129] = 5.0   # the four corners
+    assert_equal_to_oracle(oracle, gpu_op, x)
+    x = np.zeros((2, 352, 1216), np.float32)
+    x[0, 100, 100] = x[0, 300, 300] = x[0, 20, 1000] = x[0, 340, 1100] = 3.0   # long diagonal tie lines across many tiles
+    x[1, 5, 5] = 1.0
+    assert_equal_to_oracle(oracle, gpu_op, x)
+    for (H, W) in [(5, 7), (31, 33), (33, 31), (1, 100), (100, 1), (64, 257), (37, 1023)]:
+        assert_equal_to_oracle(oracle, gpu_op, pts(H, W, min(3, H * W))[None])
+    x = np.stack([pts(128, 640, 60), pts(128, 640, 30)])
+    x[0, 5, :40] = 0.5                    # values that are not sources: misaligned enumerations
+    assert_equal_to_oracle(oracle, gpu_op, x)
+    assert_equal_to_oracle(oracle, gpu_op, np.stack([pts(128, 640, 60, lo=0.7), pts(128, 640, 30, lo=0.7)]), 0.001, 0.1)  # eval_NYU.py's thresholds
+    mix = np.zeros((4, 128, 640), np.float32)
+    mix[0] = pts(128, 640, 100)
+    mix[1] = np.where(rng.random((128, 640)) < 0.05, rng.uniform(0.95, 80, (128, 640)), 0)
+    mix[2] = np.where(rng.random((128, 640)) < 0.004, rng.uniform(0.95, 80, (128, 640)), 0)
+    mix[3] = pts(128, 640, 40)
+    mix[3, :60] = 0                       # a sky over a handful of sources
+    assert_equal_to_oracle(oracle, gpu_op, mix)
+    depth, dt, lbl, status = oracle.fill_batch(mix)
+    for want in (("index",), ("dt",), ("depth",), ("depth", "dt")):
+        got = run(gpu_op, mix, want=want)
+        for k, ref in (("index", lbl), ("dt", dt), ("depth", depth)):
+            if k in want:
+                assert np.array_equal(got[k], ref), (want, k)
+
+
 def test_extreme_shapes_vs_oracle(gpu_op, oracle):
     """Shapes that stress the index arithmetic: rows wider than 4096 pixels (more than 64 bit words
     per row), tall thin frames, the largest supported H+W, and a batch with many small frames."""
