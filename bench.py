@@ -11,7 +11,9 @@ ranks itself (torch.distributed.run as a child process, before this process touc
 
 Prints ONE JSON line on rank 0, with
   roofline      the slowest kernel of the pass, timed with HIP events on the launch stream:
-                achieved = 16 B/pixel x pixels per launch / its mean duration, vs 8 TB/s HBM peak;
+                achieved = its algorithmic bytes (its bytes per pixel x the pixels it processed in this
+                pass, dtfill_pass_stats) / its mean duration, vs 8 TB/s HBM peak; `kernels` holds the
+                same figure for every kernel of the pass, `pass_frac` the whole pass at 16 B/pixel;
                 traffic = HBM bytes per launch of that kernel from the committed rocprofv3 PMC
                 passes (profiles/traffic.json, keyed by workload)
   cpu_baseline  the CPU restatement of the reference path (oracle/, kind "port") timed on this
@@ -22,7 +24,8 @@ Prints ONE JSON line on rank 0, with
                 2048^2 1 % B=16 (the per-GPU share of config 5), each with its own roofline
   repeat        the timed loop repeated (median / min / max of ms per step)
   end_to_end    what a reference-style caller sees: numpy in / numpy out through
-                DT_complete_batch, PCIe included (never `value`)
+                DT_complete_batch, PCIe included (never `value`), beside the measured pinned
+                host <-> device copy rates of the box and the bound they put on one synchronous call
   sharded       (N>1, or --sharded) fill_sharded: per-rank D2H straight into one shared pinned
                 host slab; compute and gather time
 """
@@ -125,13 +128,28 @@ def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, w
     st_ = op.run(x, path=path)["status"]
     status_bad = int(((st_ & 1) != 0).sum().item())
     general_frames = int(((st_ & 2) != 0).sum().item())
+    px = op.pass_stats()  # which kernel family owned how many pixels of that pass
     torch.cuda.synchronize()
     ms_per_step = 1e3 * elapsed / steps
     # a kernel whose blocks all exit at once still costs its dispatch (~6 us between two events): not a candidate
     live = {k: v for k, v in acc.items() if v > 0}
-    dom = max(live, key=live.get)
     algo_bytes = BYTES_PER_PIXEL * B * H * W
-    achieved = algo_bytes / (live[dom] * 1e-3) / 1e9
+    # every kernel is credited with the algorithmic bytes of the pixels IT processed (bytes per pixel of
+    # each kernel x the pixels dtfill_pass_stats says it owned), not with the whole batch
+    win = max((k for k in live if k.startswith("k_l2win")), key=lambda k: live[k], default=None)
+    per_px = {"k_mask": (4.3, px["all"]), "k_frame": (0.0, 0), "k_fused": (16.0, px["window"]), "k_pts": (12.0, px["points"]),
+              "k_colT": (0.38, px["colt"]), "k_rows": (8.85, px["anydist"]), "k_fin": (20.6, px["anydist"]), "k_tiesx": (0.0, 0),
+              "k_sky": (12.0, px["sky"]), "k_l2far": (0.0, 0), "k_l2env": (20.25, px["anydist"] + px["points"])}
+    if win:
+        per_px[win] = (16.13, px["window"])
+    kern = {}
+    for k, ms in live.items():
+        bpp, n = per_px.get(k, (0.0, 0))
+        nbytes = bpp * n
+        kern[k] = {"ms": round(ms, 4), "algorithmic_bytes": int(nbytes), "pixels": int(n),
+                   "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    dom = max(live, key=live.get)
+    achieved = kern[dom]["algorithmic_bytes"] / (live[dom] * 1e-3) / 1e9
     tr = None
     t = (traffic or {}).get(workload or "", {})  # keys of profiles/traffic.json: <workload> or <workload>_l2
     if t.get("batch") == B and dom in t.get("kernels", {}):
@@ -139,8 +157,10 @@ def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, w
         tr = k["fetch_bytes"] + k["write_bytes"]
     roof = {
         "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr, "algorithmic_bytes": algo_bytes,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr, "algorithmic_bytes": kern[dom]["algorithmic_bytes"],
+        "pass_algorithmic_bytes": algo_bytes,
         "kernel_ms": {k: round(v, 4) for k, v in live.items()},
+        "kernels": kern, "pixels_by_path": px,
         "pass_achieved_GBs": round(algo_bytes / (ms_per_step * 1e-3) / 1e9, 1),
         "pass_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "pass_traffic": t.get("pass_bytes") if t.get("batch") == B else None,
@@ -312,17 +332,23 @@ def main():
                 del xw
             line["l2"] = l2
             del op2
-            # numpy in / numpy out through the reference-named function (H2D + pass + D2H, pinned staging)
+            # numpy in / numpy out through the reference-named function (H2D + pass + D2H; returns the pinned DMA targets)
+            link = pkg.device.host_link_bandwidth()
             e2e = {}
             for nb in (1, B):
                 batch = xh[:nb, :, :, None]
                 pkg.DT_complete_batch(batch)
-                n = 20 if nb == 1 else 5
+                n = 20 if nb == 1 else 8
                 t0 = time.perf_counter()
                 for _ in range(n):
                     pkg.DT_complete_batch(batch)
                 e2e["B%d" % nb] = round(nb * n / (time.perf_counter() - t0), 1)
-            line["end_to_end"] = {"what": "DT_complete_batch numpy->numpy incl. PCIe, frames/s", **e2e}
+            # what one synchronous call cannot beat: its input over the link, the pass, its output (depth only) back
+            fb = 4 * H * W
+            bound = 1.0 / (fb / (link["h2d"] * 1e9) + res["ms_per_step"] * 1e-3 / B + fb / (link["d2h"] * 1e9))
+            line["end_to_end"] = {"what": "DT_complete_batch numpy->numpy incl. PCIe, frames/s", **e2e,
+                                  "link_GBs": {k: round(v, 1) for k, v in link.items()},
+                                  "bound_frames_per_s": round(bound, 1), "B%d_of_bound" % B: round(e2e["B%d" % B] / bound, 3)}
         if world == 1 and not args.no_cpu_baseline and args.metric == "l1_cv":
             line["cpu_baseline"] = cpu_baseline(xh)
         print(json.dumps(line))

@@ -34,6 +34,7 @@ SYMBOLS = (
     "dtfill_num_kernels",
     "dtfill_kernel_name",
     "dtfill_batch_timed",
+    "dtfill_pass_stats",
     "dtfill_outlier_removal",
     "dtfill_generate_multi_channel",
     "dtfill_crop_floor",
@@ -41,6 +42,7 @@ SYMBOLS = (
     "dtfill_metrics_workspace_bytes",
     "dtfill_metrics",
 )
+STATS = ("all", "window", "anydist", "sky", "points", "colt")  # DTFILL_STATS_*
 METRICS_KITTI = 0
 METRICS_NYU = 1
 METRICS_COLUMNS = ("mse", "rmse", "mae", "irmse", "imae", "delta1", "delta2", "delta3", "count")
@@ -96,6 +98,8 @@ def load():
     L.dtfill_kernel_name.restype = ctypes.c_char_p
     L.dtfill_batch_timed.argtypes = [vp, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, sz, vp, ctypes.c_uint, vp]
     L.dtfill_batch_timed.restype = ci
+    L.dtfill_pass_stats.argtypes = [vp, sz, ci, ci, ci, ci, vp, vp]
+    L.dtfill_pass_stats.restype = ci
     L.dtfill_outlier_removal.argtypes = [vp, ci, ci, ci, vp, vp]
     L.dtfill_outlier_removal.restype = ci
     L.dtfill_generate_multi_channel.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]

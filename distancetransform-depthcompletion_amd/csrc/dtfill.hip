@@ -497,6 +497,18 @@ int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float
     return rc;
 }
 
+int dtfill_pass_stats(const void *workspace, size_t ws_bytes, int B, int H, int W, int metric, long long *out_px, void *stream) {
+    if (!workspace || !out_px) return DTFILL_ERR_NULL;
+    if (!shape_ok(B, H, W)) return DTFILL_ERR_SHAPE;
+    if (metric != DTFILL_METRIC_L1_CV && metric != DTFILL_METRIC_L2) return DTFILL_ERR_METRIC;
+    if (ws_bytes < dtfill_workspace_bytes(B, H, W, metric) || ((uintptr_t)workspace & 255)) return DTFILL_ERR_WORKSPACE;
+    const Carve c = carve(const_cast<void *>(workspace), B, H, W);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out_px, 0, DTFILL_STATS_N * sizeof(long long), st) != hipSuccess) return DTFILL_ERR_LAUNCH;
+    k_stats<<<B, 256, 0, st>>>(c.route, c.fflag2, c.rowfar, c.finfo, H, W, metric == DTFILL_METRIC_L2 ? 1 : 0, out_px);
+    return hipGetLastError() == hipSuccess ? DTFILL_OK : DTFILL_ERR_LAUNCH;
+}
+
 int dtfill_crop_floor(const float *x, int B, int H, int W, int r0, int r1, int c0, int c1, int use_floor, float floor_,
                       float *out, void *stream) {
     if (!x || !out) return DTFILL_ERR_NULL;

@@ -145,3 +145,45 @@ __global__ __launch_bounds__(64) void k_metrics_final(const double *__restrict__
         o[8] = cnt;
     }
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// k_stats (dtfill_pass_stats): which kernel family owned how many pixels of the last pass, from the routing state the pass
+// left in the workspace.  One block per frame.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stats(const int *__restrict__ route, const int *__restrict__ fflag, const u32 *__restrict__ rowfar,
+                                               const int *__restrict__ finfo, int H, int W, int l2, long long *__restrict__ out) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int rt = route[b], r = rt > 0 ? (rt & 0xFF) : rt, ff = fflag[b];
+    const u32 t = w2_row_t(W);
+    int win = 0, any = 0, sky = 0;
+    for (int i = tid; i < H; i += 256) {
+        const u32 f = rowfar[(size_t)b * H + i];
+        if (l2) {
+            if (r > 0) {
+                if (f >= t) ++any; else ++win;
+            } else if (r == 0)
+                ++any;
+        } else if (r > 0) {
+            if (f == 2u && finfo[b * FI_STRIDE + FI_SKY] > 0) ++sky; else if (f == 0u) ++win; else ++any;
+        } else if (r == 0) {
+            if (f == 2u && finfo[b * FI_STRIDE + FI_SKY] > 0) ++sky; else ++any;
+        }
+    }
+    __shared__ int s[3];
+    if (tid < 3) s[tid] = 0;
+    __syncthreads();
+    atomicAdd(&s[0], win);
+    atomicAdd(&s[1], any);
+    atomicAdd(&s[2], sky);
+    __syncthreads();
+    if (tid == 0) {
+        auto add = [&](int k, long long v) { if (v) atomicAdd(reinterpret_cast<unsigned long long *>(out + k), (unsigned long long)v); };
+        add(DTFILL_STATS_ALL, (long long)H * W);
+        add(DTFILL_STATS_WINDOW, (long long)s[0] * W);
+        add(DTFILL_STATS_ANYDIST, (long long)s[1] * W);
+        add(DTFILL_STATS_SKY, (long long)s[2] * W);
+        add(DTFILL_STATS_POINTS, r == ROUTE_POINTS ? (long long)H * W : 0);
+        add(DTFILL_STATS_COLT, (l2 ? (r == 0 || ff == 1) : (ff == 1 || ff == 2)) ? (long long)H * W : 0);
+    }
+}

@@ -113,11 +113,26 @@ class DtFill:
         res["status"] = o["status"]
         return res
 
+    def pass_stats(self):
+        """Which kernel family owned how many pixels in the last run() of this operator (dtfill_pass_stats): dict of ints."""
+        B, H, W = self._shape
+        out = torch.zeros(len(_lib.STATS), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dtfill_pass_stats(self._ws.data_ptr() + self._ws_off, self._ws_bytes, B, H, W, self.metric, out.data_ptr(),
+                                                  torch.cuda.current_stream(self.device).cuda_stream))
+        return dict(zip(_lib.STATS, [int(v) for v in out.cpu().tolist()]))
+
     def run_numpy(self, x, src_thr=0.1, val_thr=0.1, want=WANT_ALL, depth_rows_from=0, depth_floor=None, outlier_removal=False):
         """numpy in / numpy out: H2D, run, D2H.  x: float32 [B,H,W].  Raises IndexError exactly
         where numpy would in depth_list[label_list-1] (tools.py:26) when depth is wanted.
-        The transfers go through pinned staging buffers kept per shape (the returned arrays are fresh
-        copies, as the reference's are)."""
+
+        Host side of the transfer (what a reference-style caller pays on top of the pass):
+          in   the caller's pageable array is copied into pinned staging memory a few frames at a time by a small thread
+               pool (numpy releases the GIL inside the copy), every chunk's DMA starting as soon as its copy is done;
+          out  the device-to-host DMA lands directly in the array that is returned: a page-locked buffer taken from a
+               rotating pool (_HostPool).  A buffer goes back to the pool when the caller has dropped the array it was handed
+               (and every view of it), so each call still returns arrays nothing else will ever write to -- the contract of
+               the reference, which builds fresh arrays (tools.py:29-35) -- without the extra host copy."""
         xh = np.asarray(x)
         if xh.ndim != 3:
             raise ValueError("x must be [B,H,W]")
@@ -126,44 +141,31 @@ class DtFill:
         if getattr(self, "_pin_shape", None) != (B, H, W):
             self._pin_in = torch.empty((B, H, W), dtype=torch.float32).pin_memory()
             self._dev_in = torch.empty((B, H, W), dtype=torch.float32, device=self.device)
-            self._pin_out = {
-                "depth": torch.empty((B, H, W), dtype=torch.float32).pin_memory(),
-                "dt": torch.empty((B, H, W), dtype=torch.float32).pin_memory(),
-                "index": torch.empty((B, H, W), dtype=torch.int32).pin_memory(),
-                "status": torch.empty((B,), dtype=torch.int32).pin_memory(),
-            }
+            self._pin_status = torch.empty((B,), dtype=torch.int32).pin_memory()
             self._pin_shape = (B, H, W)
-        # The transfers are pipelined against the host copies, a few frames at a time: while the CPU gathers the next chunk of
-        # the input into pinned memory the previous one is on its way to the device, and every chunk of an output is copied
-        # out of pinned memory while the next one is still crossing PCIe.
-        nchunk = min(B, 4)
+        nchunk = min(B, 8)
         cuts = [B * c // nchunk for c in range(nchunk + 1)]
         pin_in = self._pin_in.numpy()
+        pool = _copy_pool()
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device)
+            stage = [pool.submit(np.copyto, pin_in[cuts[c]:cuts[c + 1]], xh[cuts[c]:cuts[c + 1]], "same_kind") for c in range(nchunk)]
             for c in range(nchunk):
-                lo, hi = cuts[c], cuts[c + 1]
-                np.copyto(pin_in[lo:hi], xh[lo:hi], casting="same_kind")  # one pass: gathers strided input, casts if needed
-                self._dev_in[lo:hi].copy_(self._pin_in[lo:hi], non_blocking=True)
+                stage[c].result()  # (one pass: gathers strided input, casts if needed)
+                self._dev_in[cuts[c]:cuts[c + 1]].copy_(self._pin_in[cuts[c]:cuts[c + 1]], non_blocking=True)
             res = self.run(self._dev_in, src_thr, val_thr, want, depth_rows_from=depth_rows_from, depth_floor=depth_floor,
                            outlier_removal=outlier_removal)
-            self._pin_out["status"].copy_(res["status"], non_blocking=True)
-            done = []  # (name, lo, hi, event): device -> pinned copies in flight
+            self._pin_status.copy_(res["status"], non_blocking=True)
+            out = {}
             for k, v in res.items():
                 if v.dim() != 3:
                     continue
-                for c in range(nchunk):
-                    lo, hi = cuts[c], cuts[c + 1]
-                    self._pin_out[k][lo:hi, : v.shape[1]].copy_(v[lo:hi], non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(stream)
-                    done.append((k, lo, hi, ev))
-            out = {k: np.empty(tuple(v.shape), _NP_DTYPES[k]) for k, v in res.items()}
-            for k, lo, hi, ev in done:
-                ev.synchronize()
-                out[k][lo:hi] = self._pin_out[k][lo:hi, : res[k].shape[1]].numpy()
+                # contiguous in the shape that is returned (a cropped depth is [B, H - r0, W]): one DMA per output
+                host = _host_pool.take(tuple(v.shape), _NP_DTYPES[k])
+                host.tensor.copy_(v, non_blocking=True)
+                out[k] = host.array
             stream.synchronize()
-            out["status"][...] = self._pin_out["status"].numpy()
+            out["status"] = self._pin_status.numpy().copy()
         if "depth" in want:
             bad = np.nonzero(out["status"] & _lib.FRAME_INDEX_ERROR)[0]
             if bad.size:
@@ -172,6 +174,88 @@ class DtFill:
                     "(value list shorter than a label, or empty with label 0)" % int(bad[0])
                 )
         return out
+
+
+class _HostBuf:
+    __slots__ = ("tensor", "array", "alive")
+
+
+class _HostPool:
+    """Page-locked host buffers handed out as numpy arrays.  A buffer is free again once the array made from it (and every
+    view: numpy views keep their base alive) has been garbage collected; until then nobody writes to it.  At most
+    `cap_bytes` stay cached; beyond that a request gets a buffer that is simply released with its array."""
+
+    def __init__(self, cap_bytes=2 << 30):
+        import threading
+
+        self._free = {}
+        self._lock = threading.Lock()
+        self._cached = 0
+        self._cap = cap_bytes
+
+    def take(self, shape, dtype):
+        import weakref
+
+        key = (tuple(shape), np.dtype(dtype).str)
+        with self._lock:
+            lst = self._free.get(key)
+            t = lst.pop() if lst else None
+        if t is None:
+            t = torch.empty(shape, dtype=torch.from_numpy(np.empty(0, dtype)).dtype).pin_memory()
+        else:
+            with self._lock:
+                self._cached -= t.numel() * t.element_size()
+        # a fresh ndarray object over the pinned memory.  numpy collapses the base of every view (slices, expand_dims, ...) to
+        # this object, so it is alive exactly as long as anything of the caller's still looks at the buffer; when it dies the
+        # tensor goes back to the pool
+        a = t.numpy()
+        h = _HostBuf()
+        h.tensor, h.array = t, a
+        weakref.finalize(a, self._give_back, key, t)
+        return h
+
+    def _give_back(self, key, t):
+        nbytes = t.numel() * t.element_size()
+        with self._lock:
+            if self._cached + nbytes <= self._cap:
+                self._free.setdefault(key, []).append(t)
+                self._cached += nbytes
+
+
+_host_pool = _HostPool()
+_pool = None
+
+
+def _copy_pool():
+    """Threads for host-side staging copies (numpy's copy loops release the GIL)."""
+    global _pool
+    if _pool is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        _pool = ThreadPoolExecutor(max(1, min(8, n)), thread_name_prefix="dtfill-copy")
+    return _pool
+
+
+def host_link_bandwidth(nbytes=64 << 20, device=None, repeats=5):
+    """Measured pinned host <-> device copy rates of this box in GB/s: what bounds a numpy-in / numpy-out caller."""
+    _require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rates = {}
+    for name, (dst, src) in (("h2d", (d, h)), ("d2h", (h, d))):
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(repeats):
+            dst.copy_(src, non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        rates[name] = nbytes * repeats / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return rates
 
 
 def outlier_removal_device(x):

@@ -55,9 +55,10 @@ extern "C" {
                                        a label addresses past the value list, or label 0 (no source in
                                        the frame) with an empty value list.  out_depth of that frame is
                                        then unspecified; out_dt / out_index are still exact. */
-#define DTFILL_FRAME_GENERAL_PATH 2 /* informational (l1_cv): the frame was computed by the any-distance kernels
-                                       (sparse frame, or a pixel farther than 16 pixels from every source)
-                                       instead of the LDS window kernel; results are identical. */
+#define DTFILL_FRAME_GENERAL_PATH 2 /* informational (l1_cv): the frame, or some of its rows, was computed outside the LDS
+                                       window kernel -- by the any-distance kernels (sparse frame, rows with a pixel
+                                       farther than the halo from every source), k_sky (the rows above every source)
+                                       or k_pts (a handful of sources); results are identical. */
 
 /* flags of dtfill_batch_flags(): path selection, for tests and benchmarks */
 #define DTFILL_FLAG_GENERAL_ONLY 1u /* skip the window kernel, every frame takes the any-distance kernels */
@@ -125,6 +126,26 @@ const char *dtfill_kernel_name(int metric, int k);
 int dtfill_batch_timed(const float *x, int B, int H, int W, float src_thr, float val_thr, int metric,
                        float *out_depth, float *out_dt, int32_t *out_index, int32_t *frame_status,
                        void *workspace, size_t ws_bytes, void *stream, unsigned flags, float *kernel_ms);
+
+/*
+ * Which kernel family owned how many pixels in the LAST pass run in `workspace` (same B, H, W, metric) -- for bench.py's
+ * per-kernel roofline figures: a kernel is credited with the bytes of the pixels it processed, not with the whole batch.
+ * out_px: DEVICE int64[DTFILL_STATS_N], written on `stream`:
+ *   [DTFILL_STATS_ALL]     B*H*W
+ *   [DTFILL_STATS_WINDOW]  pixels of the rows the window kernel kept (l1_cv: k_fused; l2: k_l2win, rows it did not hand on)
+ *   [DTFILL_STATS_ANYDIST] pixels of the rows the any-distance kernels stored (l1_cv: k_rows / k_fin; l2: k_l2env's rows)
+ *   [DTFILL_STATS_SKY]     l1_cv: pixels of the rows k_sky stored
+ *   [DTFILL_STATS_POINTS]  pixels of the frames with a handful of sources (l1_cv: k_pts; l2: k_l2env's tiles)
+ *   [DTFILL_STATS_COLT]    pixels of the frames k_colT ran for
+ */
+#define DTFILL_STATS_ALL 0
+#define DTFILL_STATS_WINDOW 1
+#define DTFILL_STATS_ANYDIST 2
+#define DTFILL_STATS_SKY 3
+#define DTFILL_STATS_POINTS 4
+#define DTFILL_STATS_COLT 5
+#define DTFILL_STATS_N 6
+int dtfill_pass_stats(const void *workspace, size_t ws_bytes, int B, int H, int W, int metric, long long *out_px, void *stream);
 
 /*
  * outlier_removal() of the reference's loader, data_read.py:103-128 (applied in front of the path when

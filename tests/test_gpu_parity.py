@@ -1079,3 +1079,56 @@ def test_depth_epilogue_fused_into_the_stores(gpu_op, oracle, pkg):
     assert np.array_equal(pkg.DT_complete_batch(batch, first_row=96), oracle.kitti_rows(oracle.DT_complete_batch(batch)))
     one = xs[1][0]
     assert np.array_equal(pkg.Distance_Transform(one, 0.1, floor=0.9), oracle.depth_floor(oracle.Distance_Transform(one, 0.1)))
+
+
+def test_reference_functions_return_arrays_of_their_own(pkg, oracle):
+    """numpy in / numpy out through the shim: the arrays that come back are the page-locked DMA targets themselves, and a
+    later call never writes into what an earlier one returned (the reference builds fresh arrays, tools.py:29-35).  Also the
+    cropped + floored form at a real batch size (demo.py:292-293 with B = 8: several frames per transfer chunk)."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    x = synth.kitti_iid(8, p=0.05, seed=5)
+    a = pkg.DT_complete_batch(x[..., None])
+    keep = a.copy()
+    x2 = synth.kitti_scanline(8, seed=6)
+    outs = [pkg.DT_complete_batch(x2[..., None]) for _ in range(5)]  # more calls than any fixed ring of buffers
+    assert np.array_equal(a, keep) and a.dtype == np.float32 and a.shape == (8, 352, 1216, 1)
+    want2 = oracle.DT_complete_batch(x2[..., None])
+    assert all(np.array_equal(o, want2) for o in outs)
+    row = outs[0][3, 100]  # a slice keeps its buffer alive on its own
+    ref_row = row.copy()
+    del outs, a
+    for _ in range(4):
+        pkg.DT_complete_batch(x[..., None])
+    assert np.array_equal(row, ref_row)
+    got = pkg.DT_complete_batch(x2[..., None], first_row=96, floor=0.9)
+    assert got.shape == (8, 256, 1216, 1)
+    assert np.array_equal(got, oracle.depth_floor(want2[:, 96:], 0.9))
+    dt, lbl = pkg.nearest_point(x2[0])
+    d0, l0 = oracle.nearest_point(x2[0])
+    assert np.array_equal(dt, d0) and np.array_equal(lbl, l0)
+
+
+def test_config3_kitti_b256_through_fill_sharded(pkg, oracle):
+    """BASELINE.json config 3 as ONE batch: 256 KITTI frames through fill_sharded (here the group of one: every frame is this
+    GPU's; on 8 GPUs each rank takes 32 of them and the same slab is filled from 8 devices).  Properties at full size --
+    sources keep their own depth and distance 0, every filled pixel carries the depth of the source its label names, the
+    distance is the L1 distance to that source, no frame reports an error -- and three frames against the oracle."""
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    x = synth.kitti_iid(256, p=0.05, seed=1)
+    tm = {}
+    out = pkg.fill_sharded(x, timings=tm)
+    assert all(out[k].shape == (256, 352, 1216) for k in ("depth", "dt", "index"))
+    src = x >= 0.9
+    assert np.array_equal(out["depth"][src], x[src]) and (out["dt"][src] == 0).all() and (out["dt"][~src] > 0).all()
+    ii, jj = np.indices((352, 1216))
+    for b in (0, 100, 255):
+        pos = np.argwhere(src[b])
+        lab = out["index"][b]
+        assert lab.min() >= 1 and lab.max() <= len(pos)
+        si, sj = pos[lab - 1, 0], pos[lab - 1, 1]
+        assert np.array_equal(np.abs(ii - si) + np.abs(jj - sj), out["dt"][b].astype(np.int64))
+        assert np.array_equal(out["depth"][b], x[b][si, sj])
+    depth, dt, lbl, status = oracle.fill_batch(x[[3, 131, 254]])
+    for k, b in enumerate((3, 131, 254)):
+        assert np.array_equal(out["depth"][b], depth[k]) and np.array_equal(out["dt"][b], dt[k]) and np.array_equal(out["index"][b], lbl[k])
+    pkg.release_host_slab()

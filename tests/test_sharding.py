@@ -1,6 +1,8 @@
 """N>1 path on the CPU: two gloo ranks shard a batch, each fills its frames, the host gather
 reassembles them in order.  The per-rank compute is injected (the oracle stands in for the GPU
-here -- in tests only), so what is under test is shard_range + gather_frames + fill_sharded."""
+here -- in tests only), so what is under test is shard_range + gather_frames + fill_sharded: the shared slab, its rotation
+(returned arrays are never written again while anyone holds them), and the error paths (the reference's IndexError and any
+other failure of one rank's shard reach every rank; nobody waits in a collective)."""
 import os
 import socket
 import sys
@@ -63,6 +65,45 @@ def _worker(rank, world, port, n_frames, q):
         ok = ok and ("frame %d" % (n_frames - 1)) in str(e)
     only_dt = pkg.fill_sharded(xb, compute=compute, want=("dt",))  # no depth wanted: no error, as in the reference's nearest_point
     ok = ok and np.array_equal(only_dt["dt"], O.fill_batch(xb)[1])
+    # the arrays that come back ARE the shared slab: a later call must not write into what an earlier one returned (the
+    # reference returns fresh arrays, tools.py:29-35) -- a slab is reused only after every rank has dropped its arrays
+    first = pkg.fill_sharded(x, compute=compute)
+    keep = {k: v.copy() for k, v in first.items()}
+    x2 = np.roll(x, 1, axis=0)
+    second = pkg.fill_sharded(x2, compute=compute)
+    third = pkg.fill_sharded(x2, compute=compute)
+    ok = ok and all(np.array_equal(first[k], keep[k]) for k in keep)
+    ok = ok and np.array_equal(second["index"], O.fill_batch(x2)[2]) and np.array_equal(third["index"], second["index"])
+    row = first["depth"][0]  # a view keeps its slab busy on its own
+    del first, second, third
+    again = [pkg.fill_sharded(x2, compute=compute) for _ in range(6)]
+    ok = ok and np.array_equal(row, keep["depth"][0]) and all(np.array_equal(a["index"], O.fill_batch(x2)[2]) for a in again)
+    del again
+    # a shard that fails with something other than the reference's IndexError (a HIP error, a bad shape, no memory): the
+    # failing rank raises its own exception, every other rank a RuntimeError -- and none waits in a collective
+    def broken(xs, st, vt, want):
+        if rank == world - 1:
+            raise ValueError("injected shard failure")
+        return compute(xs, st, vt, want)
+
+    try:
+        pkg.fill_sharded(x, compute=broken)
+        ok = False
+    except ValueError as e:
+        ok = ok and rank == world - 1 and "injected" in str(e)
+    except RuntimeError as e:
+        ok = ok and rank != world - 1 and "rank %d" % (world - 1) in str(e)
+    ok = ok and np.array_equal(pkg.fill_sharded(x, compute=compute)["index"], idx)  # and the next call works again
+    # gather_frames under the group: any dtype, every rank or one
+    lo, hi = pkg.shard_range(n_frames, rank, world)
+    for dt_ in (np.int32, np.float32, np.float64, np.uint16):
+        data = (np.arange(n_frames * 6).reshape(n_frames, 2, 3) * 3).astype(dt_)
+        got = pkg.gather_frames(data[lo:hi], n_frames)
+        ok = ok and got.dtype == dt_ and np.array_equal(got, data)
+        got0 = pkg.gather_frames(data[lo:hi], n_frames, dst=0)
+        ok = ok and ((got0 is None) if rank else np.array_equal(got0, data))
+    leftover = [f for f in os.listdir("/dev/shm") if f.startswith("psm_")] if rank == 0 else []
+    pkg.release_host_slab()
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
@@ -79,7 +120,7 @@ def test_two_rank_gloo_gather(n_frames):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=60) for _ in procs)
+    res = dict(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
