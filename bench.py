@@ -137,9 +137,12 @@ def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, w
     # every kernel is credited with the algorithmic bytes of the pixels IT processed (bytes per pixel of
     # each kernel x the pixels dtfill_pass_stats says it owned), not with the whole batch
     win = max((k for k in live if k.startswith("k_l2win")), key=lambda k: live[k], default=None)
-    per_px = {"k_mask": (4.3, px["all"]), "k_frame": (0.0, 0), "k_fused": (16.0, px["window"]), "k_pts": (12.0, px["points"]),
-              "k_colT": (0.38, px["colt"]), "k_rows": (8.85, px["anydist"]), "k_fin": (20.6, px["anydist"]), "k_tiesx": (0.0, 0),
-              "k_sky": (12.0, px["sky"]), "k_l2far": (0.0, 0), "k_l2env": (20.25, px["anydist"] + px["points"])}
+    # (the tiles of the frames with a handful of sources -- k_pts, 12 B/px: they read a source list, not the frame -- ride in
+    # k_fused's launch)
+    per_px = {"k_mask": (4.3, px["all"]), "k_frame": (0.0, 0), "k_fused": (16.0, px["window"] + 0.75 * px["points"]),
+              "k_colT": (1.0, 0.38 * px["colt"] + 12.0 * px["sky"]),  # (k_sky's blocks ride in k_colT's launch: 12 B per sky pixel)
+              "k_rows": (8.85, px["anydist"]), "k_fin": (20.6, px["anydist"]), "k_tiesx": (0.0, 0),
+              "k_l2far": (0.0, 0), "k_l2env": (20.25, px["anydist"] + px["points"])}
     if win:
         per_px[win] = (16.13, px["window"])
     kern = {}

@@ -145,8 +145,8 @@ bool shape_ok(int B, int H, int W) {
            (long long)B * H * W < (1ll << 31);  // B is a grid dimension; pixel indices are 32-bit
 }
 
-constexpr int NK_L1 = 9;
-const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_pts", "k_colT", "k_rows", "k_fin", "k_tiesx", "k_sky"};
+constexpr int NK_L1 = 7;
+const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_colT", "k_rows", "k_fin", "k_tiesx"};
 
 // k_mask4 when the rows can be read 16 bytes at a time, k_mask otherwise (same outputs); with DTFILL_FLAG_OUTLIER_REMOVAL the
 // predicates see outlier_removal(x) (k_mask_o, then its exhaustive variant for the frames that hold a negative value)
@@ -220,29 +220,42 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         // streaming stores only where every run of tile pixels a wave stores is whole 128-byte lines
         auto line = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 127) == 0; };
         const bool stream = (W & 31) == 0 && (t16.TW & 31) == 0 && (t32.TW & 31) == 0 && line(out_depth) && line(out_dt) && line(out_index);
-        const dim3 fg(max(t16.ntiles, t32.ntiles), B);
+        // the frames with a handful of sources (k_frame: ROUTE_POINTS; only with the row flags) ride in the same launch: their
+        // 32 x 256 tiles, from the source list to the outputs (dtfill_pts.hpp); k_tiesx finishes the chains that leave a tile
+        PtsArgs pa;
+        pa.ptslist = c.ptslist;
+        pa.xlist = c.xlist;
+        pa.xptr = c.xptr;
+        pa.unres = c.planes + PL_UNRES * c.plane_bytes;
+        pa.Wp = Wd * 8;
+        pa.tiles_x = (W + Q_TW - 1) / Q_TW;
+        pa.ntiles = rowflags ? pa.tiles_x * ((H + Q_TH - 1) / Q_TH) : 0;
+        const dim3 fg(max(max(t16.ntiles, t32.ntiles), pa.ntiles), B);
         if (stream)
             k_fused<true><<<fg, F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd, t16, t32, out_depth, out_dt,
-                                               out_index, c.route, c.fflag2, status, ep);
+                                               out_index, c.route, c.fflag2, status, ep, pa);
         else
             k_fused<false><<<fg, F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd, t16, t32, out_depth, out_dt,
-                                                out_index, c.route, c.fflag2, status, ep);
+                                                out_index, c.route, c.fflag2, status, ep, pa);
     }
     mark();
     if (!fused_only) {
         // every other frame: argmin scans, any distance (dtfill_rows.hpp)
         const int nb = c.nb;
+        int cw = min(16, max(2, (nb + 3) / 4));  // two iterations of two bands per wave: fewer, longer waves fit the CUs in one round
+        // k_sky's blocks (the rows above the first source row, dtfill_sky.hpp) ride behind the column blocks
+        SkyArgs sky = {c.finfo, out_dt, out_dt_caller, out_depth, out_index, (W + SKY_SW - 1) / SKY_SW, 0};
+        size_t lds = colT_lds(nb);
         if (rowflags) {
-            // frames with a handful of sources (k_frame: ROUTE_POINTS), from the source list to the outputs; k_tiesx finishes
-            // the chains that leave a tile
-            const int ptx = (W + Q_TW - 1) / Q_TW, pty = (H + Q_TH - 1) / Q_TH;
-            k_pts<<<dim3(ptx * pty, B), Q_NT, 0, st>>>(x, c.ptslist, c.route, H, W, Wd * 8, ptx, c.vlist, out_depth, out_dt, out_index, status, c.finfo,
-                                                       c.xlist, c.xptr, c.planes + PL_UNRES * c.plane_bytes);
+            sky.nblocks = sky.nstrips * ((H + SKY_RG - 1) / SKY_RG);
+            cw = max(cw, SKY_NT / 64);
+            lds = max(lds, sky_lds(sky_span_max(H, W)));
         }
-        mark();
-        const int cw = min(16, max(2, (nb + 3) / 4));  // two iterations of two bands per wave: fewer, longer waves fit the CUs in one round
-        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, colT_lds(nb), st>>>(
-            c.srcbits, c.fflag2, H, W, Wd, nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s, (out_depth || out_index) ? c.labelmap : nullptr);
+        if (lds > 48 * 1024)  // (set per call: the attribute belongs to the current device)
+            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_colT), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        const int ncol = (c.ctp + 63) / 64;
+        k_colT<<<dim3(ncol + sky.nblocks, B), 64 * cw, lds, st>>>(c.srcbits, c.fflag2, H, W, Wd, nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s,
+                                                             (out_depth || out_index) ? c.labelmap : nullptr, ncol, sky);
         mark();
         const int Wp = Wd * 8;
         // columns per lane: 8 or 10, whichever leaves fewer idle lanes in the row's last wave
@@ -259,7 +272,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const dim3 grid(H, B);
 #define LAUNCH_ROWS(PPL_, MAXT_)                                                                                      \
     k_rows<PPL_, MAXT_><<<grid, 64 * nwv, rlds, st>>>(c.ct, c.ctp, c.fflag2, H, W, nb, Wp, c.planes, c.plane_bytes, dt,    \
-                                                   fin ? c.spix : nullptr, ovec, c.rowfar)
+                                                   fin ? c.spix : nullptr, ovec, c.rowfar, c.finfo)
         if (ten && nwv <= 4)
             LAUNCH_ROWS(10, 256);
         else if (ten)
@@ -285,16 +298,8 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
             mark();
         }
     } else {
-        for (int t = 0; t < 5; ++t) mark();
+        for (int t = 0; t < 4; ++t) mark();
     }
-    if (rowflags) {
-        const size_t lds = sky_lds(sky_span_max(H, W));
-        if (lds > 48 * 1024)  // (set per call: the attribute belongs to the current device)
-            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_sky), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-        k_sky<<<dim3((W + SKY_SW - 1) / SKY_SW, (H + SKY_RG - 1) / SKY_RG, B), SKY_NT, lds, st>>>(c.finfo, H, W, out_dt, out_dt_caller,
-                                                                                             out_depth, out_index);
-    }
-    mark();
     return ok ? DTFILL_OK : DTFILL_ERR_LAUNCH;
 }
 
@@ -335,8 +340,11 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     // vertical distances per column (k_colT) for the frames that need them: route 0, or a row handed on by k_l2win
     {
         const int cw = min(16, max(2, (c.nb + 3) / 4));
-        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, colT_lds(c.nb), st>>>(
-            c.srcbits, c.fflag2, H, W, Wd, c.nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s, (out_depth || out_index) ? c.labelmap : nullptr);
+        const size_t lds = colT_lds(c.nb);
+        if (lds > 48 * 1024)
+            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_colT), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, lds, st>>>(c.srcbits, c.fflag2, H, W, Wd, c.nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s,
+                                                         (out_depth || out_index) ? c.labelmap : nullptr, (c.ctp + 63) / 64, SkyArgs{});
     }
     mark();
     {

@@ -9,7 +9,9 @@ constexpr int MAX_HW_SUM = 8192;   // cv2's Q16 INIT_DIST0 = INT_MAX>>2 caps dis
 // frame facts written by k_frame: int32[FI_STRIDE] per frame
 constexpr int FI_NSRC = 0, FI_NVAL = 1, FI_MISALIGNED = 2, FI_DLB = 3;  // DLB: lower bound of the largest distance (empty rows)
 constexpr int FI_NUNRES = 4;  // tie pixels k_fin handed to k_tiesx (zeroed by k_frame)
-constexpr int FI_SKY = 5;     // l1_cv: rows [0, FI_SKY) hold no source and lie above every source: k_sky's (0: none)
+constexpr int FI_SKY = 5;     // l1_cv: rows [0, FI_SKY) hold no source and lie above every source: k_sky's (0: none, or called off)
+constexpr int FI_SKY0 = 6;    // ... as k_frame set it.  k_fused calls the sky off (FI_SKY = 0) when it has to hand on one of the two rows
+                              // k_sky would start from (FI_SKY0, FI_SKY0 + 1): the sky's rows then count as flagged 1
 constexpr int FI_STRIDE = 8;
 constexpr int ROUTE_POINTS = -1;  // route[b]: l2, at most L2_PTS_MAX sources in the frame (k_l2pts)
 constexpr int L2_PTS_MAX = 512;
@@ -23,7 +25,7 @@ constexpr int PTS_BAND_MAX = 96;  // l1_cv: ... and at most this many in any ban
 // its level loop to the end for a handful of their pixels)
 constexpr int ROUTE_PREMARK = 0x100;
 constexpr int PM16 = 8, PM32 = 16;
-constexpr int SKY_MIN_GENERAL = 32;  // ... of a frame the any-distance kernels take whole
+constexpr int SKY_MAX = 320;  // ... and up to this many (k_sky's blocks stage r0 + 260 columns in LDS, in k_colT's launch)
 constexpr int SKY_MIN = 9;  // rows above the first source row are k_sky's from this many on (fewer: within every window's reach)
 
 // cv2 tap order (OpenCV 3.4 distanceTransformEx_5x5), forward taps 0..7; backward tap t is the
@@ -64,3 +66,6 @@ __host__ __device__ inline size_t rowflag_offset_bytes(int B) { return ((size_t)
 __device__ __forceinline__ u32 *rowflag_of(int *fflag, int B) {
     return reinterpret_cast<u32 *>(reinterpret_cast<char *>(fflag) + rowflag_offset_bytes(B));
 }
+
+// row flag f of a frame whose sky is / is not k_sky's: is the row one of the any-distance kernels'?
+__device__ __forceinline__ bool row_is_anydist(u32 f, int sky_live) { return f == 1u || (f == 2u && !sky_live); }

@@ -122,7 +122,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     const u8 *__restrict__ s_par, const short *__restrict__ s_tab, const uint2 *__restrict__ s_rw, int b, int H,
     int W, int th, int tw, int r0, int c0, int wr0, int wc0, int sh, const float *__restrict__ x,
     const float *__restrict__ vlist,
-    const int *__restrict__ finfo, float *__restrict__ out_depth, float *__restrict__ out_dt,
+    int *__restrict__ finfo, float *__restrict__ out_depth, float *__restrict__ out_dt,
     int32_t *__restrict__ out_index, int *__restrict__ frame_status, const DepthEpilogue ep, int *__restrict__ fflag) {
     // ---- P3: tile pixels: walk to the source, d, rank -> label, gather, store.  Each lane walks F_EB
     // pixels in lock-step (their LDS reads are independent, so the hop latencies overlap) and then has
@@ -267,7 +267,12 @@ __device__ __forceinline__ bool fused_walk_epilogue(
         u32 *rowflag = rowflag_of(fflag, (int)gridDim.y);  // the workspace keeps the row flags right behind the frame flags
         for (int p = threadIdx.x; p < npx; p += NT) {
             const int tr = p / tw, tc = p - tr * tw;
-            if (s_par[__mul24(FR + tr, F_P) + FR + tc] == F_NONE) rowflag[(size_t)b * H + r0 + tr] = 1u;  // same-value race
+            if (s_par[__mul24(FR + tr, F_P) + FR + tc] == F_NONE) {
+                rowflag[(size_t)b * H + r0 + tr] = 1u;  // same-value race
+                // one of the two rows k_sky starts from: the any-distance kernels take the sky's rows as well
+                const int s0 = finfo[b * FI_STRIDE + FI_SKY0];
+                if (s0 > 0 && (r0 + tr == s0 || r0 + tr == s0 + 1)) finfo[b * FI_STRIDE + FI_SKY] = 0;
+            }
         }
     }
     return any;
@@ -549,20 +554,43 @@ __device__ __forceinline__ void fused_body(bool premarked,
 // sized for the halo-32 tiling (more, smaller tiles); blocks beyond a frame's own tiling exit.  A tile pixel that turns out
 // to be farther than the halo from every source is not stored: its ROW is handed to the any-distance kernels (rowflag,
 // fflag = 1; frame_status), which redo exactly those rows -- the empty sky of a LiDAR frame, a hole in a dense one.
+// the block's LDS: one buffer, carved here for the window kernel and in dtfill_pts.hpp for a k_pts tile
+constexpr size_t F_OFF_RW = (sizeof(u32) * F_RING + 15) & ~(size_t)15, F_OFF_TAB = F_OFF_RW + sizeof(uint2) * F_WHM * 8, F_OFF_ANY = F_OFF_TAB + sizeof(short) * 64,
+                 F_LDS_OWN = F_OFF_ANY + sizeof(u32) * 2 * (F_NT / 64);
+constexpr size_t F_LDS = F_LDS_OWN < 38736 ? 38736 : F_LDS_OWN;  // (>= PTS_LDS: checked where that is defined)
+
+struct PtsArgs {  // what a k_pts tile needs beyond the window kernel's own arguments
+    const PtsSrc *ptslist;
+    u32 *xlist, *xptr;
+    u8 *unres;
+    int Wp, tiles_x, ntiles;
+};
+__device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, const float *__restrict__ x, const PtsSrc *__restrict__ ptslist, int H,
+                                         int W, int Wp, int tiles_x, const float *__restrict__ vlist, float *__restrict__ out_depth,
+                                         float *__restrict__ out_dt, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
+                                         int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres);
+
 template <bool STREAM>
 __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
     int H, int W, int Wd, FusedTiles t16, FusedTiles t32, float *__restrict__ out_depth,
     float *__restrict__ out_dt, int32_t *__restrict__ out_index,
-    const int *__restrict__ route, int *__restrict__ fflag, int *__restrict__ frame_status, const DepthEpilogue ep) {
-    __shared__ __attribute__((aligned(16))) u32 s_ring[F_RING];  // later: s_par bytes
+    const int *__restrict__ route, int *__restrict__ fflag, int *__restrict__ frame_status, const DepthEpilogue ep, const PtsArgs pa) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[F_LDS];
+    u32 *s_ring = reinterpret_cast<u32 *>(s_raw);  // later: s_par bytes
     // per window row, the eight image-aligned 32-pixel half words it touches: {source bits, sources before them
     // in frame raster order} -- one 8-byte LDS read and a 32-bit popcount per rank lookup
-    __shared__ uint2 s_rw[F_WHM * 8];
-    __shared__ short s_tab[64];      // s_par displacement of the step enc (0 for the codes that are no step)
-    __shared__ u32 s_any[2][F_NT / 64];  // per wave: did level t produce anything (double-buffered by level parity)
+    uint2 *s_rw = reinterpret_cast<uint2 *>(s_raw + F_OFF_RW);
+    short *s_tab = reinterpret_cast<short *>(s_raw + F_OFF_TAB);  // s_par displacement of the step enc (0 for the codes that are no step)
+    u32(*s_any)[F_NT / 64] = reinterpret_cast<u32(*)[F_NT / 64]>(s_raw + F_OFF_ANY);  // per wave: did level t produce anything (double-buffered by level parity)
     const int rt = route[blockIdx.y];        // block-uniform
+    if (rt == ROUTE_POINTS) {
+        // a frame with a handful of sources: its 32 x 256 tiles ride in this launch (dtfill_pts.hpp)
+        if ((int)blockIdx.x < pa.ntiles)
+            pts_body(s_raw, x, pa.ptslist, H, W, pa.Wp, pa.tiles_x, vlist, out_depth, out_dt, out_index, frame_status, finfo, pa.xlist, pa.xptr, pa.unres);
+        return;
+    }
     const int r = rt > 0 ? (rt & 0xFF) : 0;
     const bool pre = rt > 0 && (rt & ROUTE_PREMARK);
     const bool epi = ep.row0 != 0 || ep.use_floor;  // uniform: the plain pass runs code compiled without the epilogue

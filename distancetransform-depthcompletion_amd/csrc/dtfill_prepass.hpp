@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     __syncthreads();
     const int misaligned = s_mis;
     const int r0 = s_r0;
-    const bool sky_ok = premark && r0 >= SKY_MIN && r0 < H;  // rows [0, r0) can be k_sky's
+    const bool sky_ok = premark && r0 >= SKY_MIN && r0 <= SKY_MAX && r0 < H;  // rows [0, r0) can be k_sky's
     if (tid == 0) {
         // Which kernel family takes the frame -- a speed heuristic, never a correctness condition (the window kernels hand on
         // every row in which they meet a pixel they cannot decide).  With source density p the chance that a pixel has no
@@ -425,8 +425,9 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         }
     }
     const bool flags = !l2 && premark && r >= 0;  // this frame's rows carry flags
-    // a frame that goes to the any-distance kernels whole gains from k_sky only what a deep sky saves them
-    const bool sky = sky_ok && (r > 0 || r0 >= SKY_MIN_GENERAL);
+    // k_sky starts from rows r0 and r0 + 1 as the window kernel leaves them (it runs beside the first any-distance kernel): a
+    // frame that is not a window kernel's, or whose row r0 / r0 + 1 is handed on up front, keeps its sky with the other rows
+    bool sky = sky_ok && r > 0;
     u32 *far = s_far[r == 32 ? 1 : 0];
     if (flags && r > 0) {
         // a tile row of the window kernel that is left with only a few rows is not worth its windows: all of it goes to the
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
             return hi <= lo ? 0u : (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
         };
         for (int t = tid; t * TH < H; t += 256) {
-            const int a = max(t * TH, sky ? r0 : 0), e = min(H, (t + 1) * TH);  // its rows below the sky
+            const int a = max(t * TH, sky_ok ? r0 : 0), e = min(H, (t + 1) * TH);  // its rows below the sky
             int keep = 0;
             for (int w = a >> 5; w <= (e - 1) >> 5 && a < e; ++w) keep += __popc(~far[w] & bits(a, e, w));
             if (keep && 4 * keep <= min(H, (t + 1) * TH) - t * TH)
@@ -445,12 +446,13 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         }
     }
     __syncthreads();
+    if (sky && (((far[r0 >> 5] >> (r0 & 31)) & 1u) || (r0 + 1 < H && ((far[(r0 + 1) >> 5] >> ((r0 + 1) & 31)) & 1u)))) sky = false;
     // per row: l1_cv: 0 = the window kernel's, 1 = the any-distance kernels' (pre-marked here, or set by k_fused when it meets
     // a pixel farther than its halo), 2 = k_sky's; l2: far pixels k_l2win counted
     bool one = false;
     for (int i = tid; i < H; i += 256) {
         u32 f = 0u;
-        if (flags) f = (sky && i < r0) ? 2u : r == 0 ? (sky ? 1u : 0u) : (far[i >> 5] >> (i & 31)) & 1u;
+        if (flags && r > 0) f = i < r0 && sky_ok ? (sky ? 2u : 1u) : (far[i >> 5] >> (i & 31)) & 1u;
         one |= f == 1u;
         rowfar[(size_t)b * H + i] = f;
     }
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         finfo[b * FI_STRIDE + FI_MISALIGNED] = misaligned;
         finfo[b * FI_STRIDE + FI_DLB] = s_dlb;
         finfo[b * FI_STRIDE + FI_NUNRES] = 0;
-        finfo[b * FI_STRIDE + FI_SKY] = (flags && sky) ? r0 : 0;
+        finfo[b * FI_STRIDE + FI_SKY] = finfo[b * FI_STRIDE + FI_SKY0] = (flags && sky) ? r0 : 0;
         const bool marked = flags && r > 0 && (sky || any1);
         route[b] = marked ? (r | ROUTE_PREMARK) : r;
         negflag[b] = 0;  // k_mask_o's "this frame holds a negative value": consumed before this kernel, reset for the next pass
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         // 2: the any-distance kernels take the whole frame; 1: the rows flagged 1 (pre-marked here, or by k_fused, or (l2) by
         // k_l2win when it hands a row of far pixels on); 0: nothing for them
         // 3 (l1_cv, ROUTE_POINTS): k_pts takes the frame, of the any-distance kernels only k_tiesx has something to do
-        fflag2[b] = (!l2 && r == ROUTE_POINTS) ? 3 : general ? ((flags && sky) ? 1 : 2) : (flags && any1) ? 1 : 0;
+        fflag2[b] = (!l2 && r == ROUTE_POINTS) ? 3 : general ? 2 : (flags && any1) ? 1 : 0;
         frame_status[b] = (general || r == ROUTE_POINTS || marked) ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
     }
     if (misaligned) {

@@ -1,4 +1,4 @@
-// dtfill_pts.hpp -- k_pts: l1_cv frames with a handful of sources (the NYU sampling patterns), one kernel from the source
+// dtfill_pts.hpp -- pts_body ("k_pts"): l1_cv frames with a handful of sources (the NYU sampling patterns), one kernel from the source
 // list to the three outputs
 // Part of libdtfill.so; included by dtfill.hip inside its anonymous namespace (one translation unit), after dtfill_rows.hpp
 // (the bit-sliced parent rule rule_tap / step_tap and the tile geometry Q_* are k_fin's).
@@ -39,20 +39,24 @@ __device__ __forceinline__ u32 med3u(u32 a, u32 b, u32 c) {
     return r;
 }
 
-__global__ __launch_bounds__(Q_NT, 4) void k_pts(const float *__restrict__ x, const PtsSrc *__restrict__ ptslist, const int *__restrict__ route, int H, int W, int Wp,
-                                                 int tiles_x, const float *__restrict__ vlist, float *__restrict__ out_depth,
-                                                 float *__restrict__ out_dt, int32_t *__restrict__ out_index,
-                                                 int *__restrict__ frame_status, int *__restrict__ finfo, u32 *__restrict__ xlist,
-                                                 u32 *__restrict__ xptr, u8 *__restrict__ unres) {
-    __shared__ u32 s_pl[6][P_NR][Q_RS];        // d bit 0, 1, 2, live, tie, in-image; rows r0-2 .. r0+33; word 0 / 9: the ring's
-    __shared__ __attribute__((aligned(16))) u8 s_byte[Q_TH][Q_TW];  // per tile pixel: step to its parent; before that: the waves' candidate lists
-    __shared__ u16 s_src[P_NR][P_SP];          // per box pixel: list index of its nearest source (the smallest index)
-    __shared__ u32 s_rc[PTS_MAX];              // the frame's sources: row << 16 | column
-    __shared__ u8 s_list[Q_NT];                // the listed words (phase 4)
-    __shared__ u32 s_cnt[Q_NT / 64];
-    static_assert(sizeof(s_byte) >= (Q_NT / 64) * PTS_MAX * sizeof(u16), "the candidate lists live in s_byte until the planes are done");
+// LDS of one block, carved from the window kernel's buffer (the tiles of such frames ride in k_fused's launch)
+constexpr size_t P_OFF_BYTE = sizeof(u32) * 6 * P_NR * Q_RS, P_OFF_SRC = P_OFF_BYTE + Q_TH * Q_TW, P_OFF_RC = P_OFF_SRC + sizeof(u16) * P_NR * P_SP,
+                 P_OFF_LIST = P_OFF_RC + sizeof(u32) * PTS_MAX, P_OFF_CNT = P_OFF_LIST + Q_NT, PTS_LDS = P_OFF_CNT + sizeof(u32) * (Q_NT / 64);
+static_assert(P_OFF_BYTE % 16 == 0 && P_OFF_SRC % 4 == 0 && P_OFF_RC % 4 == 0 && P_OFF_CNT % 4 == 0, "alignment of the carve");
+static_assert(PTS_LDS <= F_LDS, "k_fused's buffer holds a k_pts block");
+
+__device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, const float *__restrict__ x, const PtsSrc *__restrict__ ptslist, int H,
+                                         int W, int Wp, int tiles_x, const float *__restrict__ vlist, float *__restrict__ out_depth,
+                                         float *__restrict__ out_dt, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
+                                         int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres) {
+    u32(*s_pl)[P_NR][Q_RS] = reinterpret_cast<u32(*)[P_NR][Q_RS]>(s_raw);  // d bit 0, 1, 2, live, tie, in-image; rows r0-2 .. r0+33; word 0 / 9: the ring's
+    u8(*s_byte)[Q_TW] = reinterpret_cast<u8(*)[Q_TW]>(s_raw + P_OFF_BYTE);  // per tile pixel: step to its parent; before that: the waves' candidate lists
+    u16(*s_src)[P_SP] = reinterpret_cast<u16(*)[P_SP]>(s_raw + P_OFF_SRC);  // per box pixel: list index of its nearest source | plane bits << 9
+    u32 *s_rc = reinterpret_cast<u32 *>(s_raw + P_OFF_RC);                 // the frame's sources: row << 16 | column; later their depths
+    u8 *s_list = s_raw + P_OFF_LIST;                                        // the listed words (phase 4)
+    u32 *s_cnt = reinterpret_cast<u32 *>(s_raw + P_OFF_CNT);
+    static_assert(Q_TH * Q_TW >= (Q_NT / 64) * PTS_MAX * sizeof(u16), "the candidate lists live in s_byte until the planes are done");
     const int b = blockIdx.y, tid = threadIdx.x;
-    if (route[b] != ROUTE_POINTS) return;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * Q_TH, c0 = tx * Q_TW;
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(Q_NT, 4) void k_pts(const float *__restrict__ x, co
     // ---- 1 + 2. this wave's candidates: box = rows r0 - 2 .. r0 + 33, columns wc0 - 2 .. wc0 + 65 (the edge waves' ring columns).
     // The list holds indices into the frame's list, in raster order (the frame's list is, and every compaction keeps it).
     const int wc0 = c0 + 64 * wave;
-    u16 *wc = reinterpret_cast<u16 *>(&s_byte[0][0]) + wave * PTS_MAX;
+    u16 *wc = reinterpret_cast<u16 *>(s_raw + P_OFF_BYTE) + wave * PTS_MAX;
     int nw = 0;  // wave-uniform
     {
         // doubled coordinates: the centre sits on a half pixel

@@ -140,12 +140,28 @@ __device__ __forceinline__ void colT_block(const u64 *__restrict__ srcbits, cons
         }
 }
 
+struct SkyArgs {  // k_sky's blocks ride behind k_colT's (l1_cv with row flags): see dtfill_sky.hpp
+    const int *finfo;
+    const float *dt_src;
+    float *out_dt, *out_depth;
+    int32_t *out_index;
+    int nstrips, nblocks;  // blocks = strips x row groups; 0: none
+};
+__device__ __forceinline__ void sky_body(unsigned char *s_sky, const int *__restrict__ finfo, int H, int W, const float *dt_src, float *out_dt,
+                                         float *out_depth, int32_t *out_index, int strip, int rowgroup);
+
 __global__ __launch_bounds__(1024) void k_colT(const u64 *__restrict__ srcbits, const int *__restrict__ fflag, int H,
                                                int W, int Wd, int nb, int CTP, uint2 *__restrict__ ct,
                                                const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
-                                               int32_t *__restrict__ labelmap) {
-    extern __shared__ u16 s_lf[];
+                                               int32_t *__restrict__ labelmap, int ncolblocks, const SkyArgs sky) {
+    extern __shared__ __attribute__((aligned(16))) u16 s_lf[];
     __shared__ u64 s_rowword[16][64];
+    if ((int)blockIdx.x >= ncolblocks) {  // (block-uniform)
+        const int k = (int)blockIdx.x - ncolblocks;
+        sky_body(reinterpret_cast<unsigned char *>(s_lf), sky.finfo, H, W, sky.dt_src, sky.out_dt, sky.out_depth, sky.out_index, k % sky.nstrips,
+                 k / sky.nstrips);
+        return;
+    }
     colT_block(srcbits, fflag, H, W, Wd, nb, CTP, ct, wpre_s, rowbase_s, labelmap, (int)blockIdx.x, s_lf, s_rowword);
 }
 
@@ -257,7 +273,7 @@ template <int PPL, int MAXT>  // MAXT: 256 (rows of up to 4 waves; 3 waves per S
 __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
     const uint2 *__restrict__ ct, int CTP, const int *__restrict__ fflag, int H, int W, int nb, int Wp,
     u8 *__restrict__ planes, size_t plane_bytes, float *__restrict__ out_dt, u32 *__restrict__ spix_out, int ovec,
-    const u32 *__restrict__ rowflag) {
+    const u32 *__restrict__ rowflag, const int *__restrict__ finfo_sky) {
     static_assert(PPL == 8 || PPL == 10, "loads and stores below are written for 8 or 10 columns per lane");
     __shared__ u32 s_tot[R_MAXWV][6];
     __shared__ u32 s_bits[5][R_MAXPW + 1];
@@ -267,7 +283,8 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
     if (!ff || ff == 3) return;  // block-uniform (3: k_pts's frame)
     if (ff == 1) {    // only near a row k_fused could not finish
         const int rr = i - R_MARGIN + lane;
-        if (!__any(lane <= 2 * R_MARGIN && rr >= 0 && rr < H && rowflag[(size_t)b * H + rr] == 1u)) return;
+        const int sky_live = finfo_sky[b * FI_STRIDE + FI_SKY];
+        if (!__any(lane <= 2 * R_MARGIN && rr >= 0 && rr < H && row_is_anydist(rowflag[(size_t)b * H + rr], sky_live))) return;
     }
     const int band = i >> 5, r = i & 31;
     const int idx0 = (wv * 64 + lane) * PPL;
@@ -548,7 +565,8 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     u32 coremask = 0xFFFFFFFFu;
     if (ff == 1) {
         const int l = tid & 63;
-        coremask = (u32)__ballot(l < Q_TH && r0 + l < H && rowflag[(size_t)b * H + min(r0 + l, H - 1)] == 1u);
+        const int sky_live = finfo[b * FI_STRIDE + FI_SKY];
+        coremask = (u32)__ballot(l < Q_TH && r0 + l < H && row_is_anydist(rowflag[(size_t)b * H + min(r0 + l, H - 1)], sky_live));
         if (!coremask) return;  // block-uniform: every wave computes the same mask
     }
     const int wpr = Wp >> 2;  // 32-pixel words per plane row
@@ -849,7 +867,7 @@ __global__ __launch_bounds__(256) void k_tiesx(const u8 *__restrict__ unres, int
         for (int step = 0; step < H * W; ++step) {  // every step ends on a pixel nearer to the sources
             const u32 pi = p / (u32)W, pj = p - pi * (u32)W;
             // a row that was not redone holds k_fused's finished pixels (and no "unresolved" bits of this pass)
-            const bool redone = ff != 1 || rowflag[rowb + pi] == 1u;
+            const bool redone = ff != 1 || row_is_anydist(rowflag[rowb + pi], finfo[b * FI_STRIDE + FI_SKY]);
             const u32 open = (unres[(rowb + pi) * Wp + (pj >> 3)] >> (pj & 7u)) & 1u;
             const u32 nx = xptr[fo + p];  // meaningful only if open
             if (!redone || !open) break;

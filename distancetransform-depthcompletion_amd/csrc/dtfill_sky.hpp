@@ -19,6 +19,8 @@
 //     t = min(run length of column j, floor((r0 - i) / 2))
 // hops of (+2, +-1) and lands in row i + 2 t, column j +- t: in row r0 on that base pixel itself, in any row above on what row
 // r0 - 1 holds in that column -- O(1) per pixel, every pixel independent (tests/parallel_model.py::sky_rows_closed_form).
+// The blocks ride behind k_colT's in its launch (the first launch after the window kernel, whose rows r0 and r0 + 1 they read;
+// should the window kernel have had to hand one of those on, it has called the sky off and the any-distance kernels take its rows).
 // A block takes SKY_RG rows x SKY_SW columns of one frame's sky: it stages f, the base rows' (label, depth) pairs and row
 // r0 - 1's pairs for its columns and the columns its hops can reach in LDS, then every thread stores its column's SKY_RG
 // pixels.  Reads the base rows from the pass's own outputs (dt from the scratch when the caller wants none).
@@ -26,19 +28,18 @@
 constexpr int SKY_NT = 256;  // threads = columns of a block
 constexpr int SKY_SW = 256;
 constexpr int SKY_RG = 16;   // rows of a block
-__host__ __device__ inline int sky_span_max(int H, int W) { return min(W, SKY_SW + 2 * (H / 2) + 4); }
+__host__ __device__ inline int sky_span_max(int H, int W) { return min(W, SKY_SW + 2 * (min(H, SKY_MAX) / 2) + 4); }
 __host__ __device__ inline size_t sky_lds(int span) { return (size_t)((span + 7) & ~7) * (2 * sizeof(u16) + 3 * sizeof(uint2)); }
 
-__global__ __launch_bounds__(SKY_NT) void k_sky(const int *__restrict__ finfo, int H, int W, const float *dt_src, float *out_dt,
-                                                float *out_depth, int32_t *out_index) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_sky[];
-    const int b = blockIdx.z, tid = threadIdx.x;
+__device__ __forceinline__ void sky_body(unsigned char *s_sky, const int *__restrict__ finfo, int H, int W, const float *dt_src, float *out_dt,
+                                         float *out_depth, int32_t *out_index, int strip, int rowgroup) {
+    const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;  // (at least SKY_NT threads: the host sees to it)
     const int r0 = finfo[b * FI_STRIDE + FI_SKY];
-    const int i0 = blockIdx.y * SKY_RG;
-    if (r0 <= 0 || r0 >= H || i0 >= r0) return;  // block-uniform: no sky in this frame, or not this far down
+    const int i0 = rowgroup * SKY_RG;
+    if (r0 <= 0 || r0 >= H || i0 >= r0) return;  // block-uniform: no sky in this frame (or called off), or not this far down
     const int i1 = min(i0 + SKY_RG, r0);
     const int T = (r0 - i0) / 2;  // the most hops a pixel of these rows takes
-    const int c0 = blockIdx.x * SKY_SW, c1 = min(W, c0 + SKY_SW);  // the columns this block stores
+    const int c0 = strip * SKY_SW, c1 = min(W, c0 + SKY_SW);  // the columns this block stores
     // the columns it looks at: its own, the T columns either side a hop chain can end in, and what row r0 - 1's rule reads
     // around those (one column to the left, two to the right)
     const int lo = max(0, c0 - T - 1), hi = min(W, c1 + T + 3), n = hi - lo;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(SKY_NT) void k_sky(const int *__restrict__ finfo, i
     u16 *s_f1 = s_f0 + Np;                              // [Np] d(r0 + 1, .); 0xFFFF without such a row
     const size_t fo = (size_t)b * H * W;
     const bool two = r0 + 1 < H;
-    for (int k = tid; k < n; k += SKY_NT) {
+    for (int k = tid; k < n; k += NT) {
         const size_t o0 = fo + (size_t)r0 * W + lo + k, o1 = o0 + (two ? W : 0);
         s_f0[k] = (u16)dt_src[o0];
         s_f1[k] = two ? (u16)dt_src[o1] : (u16)0xFFFF;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(SKY_NT) void k_sky(const int *__restrict__ finfo, i
     __syncthreads();
     // row r0 - 1: the five leading backward taps on the real distances (a span edge inside the frame yields a stale entry that
     // no hop chain of this block can end in)
-    for (int k = tid; k < n; k += SKY_NT) {
+    for (int k = tid; k < n; k += NT) {
         const int D = (int)s_f0[k] + 1;
         const int fp1 = k + 1 < n ? (int)s_f0[k + 1] : BIG, fp2 = k + 2 < n ? (int)s_f0[k + 2] : BIG;
         const int gp1 = k + 1 < n ? (int)s_f1[k + 1] : BIG, gm1 = k >= 1 ? (int)s_f1[k - 1] : BIG;

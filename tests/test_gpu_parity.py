@@ -939,6 +939,11 @@ def test_rows_marked_up_front_for_the_any_distance_kernels(gpu_op, oracle, pkg):
             if rng.random() < 0.5:
                 a[i + 5, j + 5] = 4.0
         frames.append(a)
+        a = rings(H, W, min(100, H - 40), 4, 0.25)                      # the first source row holds ONE stray source, the rings start
+        a[min(70, H - 70)] = 0                                           # 30 rows further down: the window kernel cannot finish
+        a[min(70, H - 70), W // 3] = 2.5                                 # that row, so it calls the sky off
+        a[:min(70, H - 70)] = 0
+        frames.append(a)
         x = np.stack(frames)
         assert_equal_to_oracle(oracle, gpu_op, x)
         assert_equal_to_oracle(oracle, gpu_op, x[:4], st=0.1, vt=30.0)  # value list differs from the source list
