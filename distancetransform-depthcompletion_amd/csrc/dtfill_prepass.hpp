@@ -114,7 +114,8 @@ __device__ __forceinline__ u64 row_word(u32 nib, int lane) {
 // and the pixels it removes read as 0.0f below.  OM == 1 raises negflag[b] on a negative value, the OM == 2 launch redoes
 // exactly those frames.
 __device__ __forceinline__ bool outlier_at(const float *__restrict__ xf, int H, int W, int i, int j, float v);
-template <int OM>
+template <int OM, int R>  // R image rows per wave, the loads of all of them in flight before the first is worked on (R = 2 measured no
+                          // faster than 1 on the KITTI batch: the kernel is not short of bytes in flight; only R = 1 is launched)
 __global__ __launch_bounds__(256) void k_mask4(const float *__restrict__ x, int H, int W, int Wd, float src_thr,
                                                float val_thr, u64 *__restrict__ srcbits, u64 *__restrict__ valbits,
                                                u16 *__restrict__ wpre_s, u16 *__restrict__ wpre_v,
@@ -122,21 +123,41 @@ __global__ __launch_bounds__(256) void k_mask4(const float *__restrict__ x, int 
     __shared__ u16 s_list[OM ? 4 : 1][OM ? M4_NC * 256 : 1];
     __shared__ u32 s_drop[OM ? 4 : 1][OM ? M4_NC * 8 : 1];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i = blockIdx.x * 4 + wave, b = blockIdx.y;
-    if (i >= H) return;
+    const int i0 = (blockIdx.x * 4 + wave) * R, b = blockIdx.y;
+    if (i0 >= H) return;
     if (OM == 2 && !negflag[b]) return;
     bool neg = false;
+    const int w_in_chunk = lane >> 4;  // which of the chunk's four words this lane's row builds
+    const int nchunk = (W + 255) >> 8;
+    // rows of at most M4_NC chunks (2048 pixels) with R > 1: the first batch of every row is loaded up front
+    float4 pre[R][M4_NC];
+    if (R > 1) {
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const float4 *rowp = reinterpret_cast<const float4 *>(x + ((size_t)b * H + min(i0 + rr, H - 1)) * W);
+#pragma unroll
+            for (int u = 0; u < M4_NC; ++u) {
+                const int px = (u << 8) + 4 * lane;
+                pre[rr][u] = (u < nchunk && px < W) ? rowp[px >> 2] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+    }
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    const int i = i0 + rr;
+    if (i >= H) break;  // wave-uniform
     const float4 *row = reinterpret_cast<const float4 *>(x + ((size_t)b * H + i) * W);
     const size_t wrow = ((size_t)b * H + i) * Wd;
-    const int w_in_chunk = lane >> 4;  // which of the chunk's four words this lane's row builds
     u32 run_s = 0, run_v = 0, mis = 0;  // wave-uniform
-    const int nchunk = (W + 255) >> 8;
     for (int c0 = 0; c0 < nchunk; c0 += M4_NC) {
         float4 v[M4_NC];
 #pragma unroll
         for (int u = 0; u < M4_NC; ++u) {
             const int px = ((c0 + u) << 8) + 4 * lane;
-            v[u] = (c0 + u < nchunk && px < W) ? row[px >> 2] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (R > 1 && c0 == 0)
+                v[u] = pre[rr][u];
+            else
+                v[u] = (c0 + u < nchunk && px < W) ? row[px >> 2] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         if (OM) {
             if (lane < M4_NC * 8) s_drop[wave][lane] = 0u;
@@ -201,11 +222,12 @@ __global__ __launch_bounds__(256) void k_mask4(const float *__restrict__ x, int 
             run_v += v0 + v1 + v2 + v3;
         }
     }
-    if (OM == 1 && __any(neg) && lane == 0) negflag[b] = 1;  // this frame is redone by the exhaustive launch
     if (lane == 0) {
         rowcnt_s[(size_t)b * H + i] = run_s;
         rowcnt_v[(size_t)b * H + i] = run_v | (mis ? 0x80000000u : 0u);
     }
+  }
+    if (OM == 1 && __any(neg) && lane == 0) negflag[b] = 1;  // this frame is redone by the exhaustive launch
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -233,14 +255,22 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 *cs_ = rowcnt_s + (size_t)b * H, *cv_ = rowcnt_v + (size_t)b * H;
     u32 *bs_ = rowbase_s + (size_t)b * H, *bv_ = rowbase_v + (size_t)b * H;
+    __shared__ u32 s_empty[256];   // bit i: row i holds no source (the rows past H count as empty)
+    __shared__ u32 s_far[2][256];  // bit i: row i >= r0 and vd(i) > PM16 / > PM32
+    __shared__ int s_nfar[2], s_r0, s_route, s_bandmax;
+    const int Hp = (H + 63) & ~63;
     if (tid == 0) {
         s_mis = 0;
         s_dlb = 0;
+        s_r0 = H;
+        s_bandmax = 0;
     }
+    if (tid < 2) s_nfar[tid] = 0;
+    for (int w = tid + (Hp >> 5); w < 256; w += 256) s_empty[w] = 0xFFFFFFFFu;
     __syncthreads();
     u32 run_s = 0, run_v = 0;
     int mis = 0;
-    for (int base = 0; base < H; base += 256) {
+    for (int base = 0; base < Hp; base += 256) {
         const int i = base + tid;
         u32 cs = 0, cv = 0;
         if (i < H) {
@@ -248,6 +278,20 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
             cv = cv_[i];
             mis |= (int)(cv >> 31);
             cv &= 0x7FFFFFFFu;
+        }
+        {
+            // the same pass over the row counts: "row has no source" as bits (a wave holds 64 consecutive rows: two whole words per
+            // ballot, no atomics), the first row with a source, the most sources in a band of 32 rows (k_pts's tiles are that high)
+            const u64 has = __ballot(cs != 0u), bal = ~has;
+            if (lane == 0 && i < Hp) {
+                s_empty[i >> 5] = (u32)bal;
+                s_empty[(i >> 5) + 1] = (u32)(bal >> 32);
+                if (has) atomicMin(&s_r0, i + __ffsll((long long)has) - 1);
+            }
+            u32 c = cs;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) c += (u32)__shfl_xor((int)c, o);
+            if ((lane & 31) == 0 && c) atomicMax(&s_bandmax, (int)c);
         }
         u32 is = cs, iv = cv;
 #pragma unroll
@@ -291,39 +335,11 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     //          vd above a window kernel's reach (PM16 / PM32) cannot be decided by it: it is handed to the any-distance kernels
     //          up front (flag 1), and the window kernel takes the rest of the frame instead of nothing.
     // "Row has no source" as bits in LDS (H <= 8191 -> 256 words); the rows past H count as empty.
-    __shared__ u32 s_empty[256];
-    __shared__ u32 s_far[2][256];  // bit i: row i >= r0 and vd(i) > PM16 / > PM32
-    __shared__ int s_nfar[2], s_r0, s_route, s_bandmax;
     {
-        // a wave holds 64 consecutive rows: the row bits leave as two whole words per ballot, no atomics
-        const int Hp = (H + 63) & ~63;
-        if (tid < 2) s_nfar[tid] = 0;
-        if (tid == 0) {
-            s_r0 = H;
-            s_bandmax = 0;
-        }
-        for (int w = tid + (Hp >> 5); w < 256; w += 256) s_empty[w] = 0xFFFFFFFFu;
-        __syncthreads();
-        for (int base = 0; base < Hp; base += 256) {
-            const int i = base + tid;
-            const u64 has = __ballot(i < H && cs_[min(i, H - 1)] != 0), bal = ~has;  // empty, or past the frame
-            if (lane == 0 && i < Hp) {
-                s_empty[i >> 5] = (u32)bal;
-                s_empty[(i >> 5) + 1] = (u32)(bal >> 32);
-                if (has) atomicMin(&s_r0, i + __ffsll((long long)has) - 1);
-            }
-        }
-        __syncthreads();
         int dlb = 0;
         const int lastw = (H - 1) >> 5, r0 = s_r0;
         for (int base = 0; base < Hp; base += 256) {
             const int i = base + tid;
-            {   // sources per band of 32 rows (k_pts's tiles are that high): the largest one
-                u32 c = i < H ? cs_[i] : 0u;
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) c += (u32)__shfl_xor((int)c, o);
-                if ((lane & 31) == 0 && c) atomicMax(&s_bandmax, (int)c);
-            }
             int vd = 0;
             if (i < H) {
                 int up = BIG, dn = BIG;  // distance to the nearest row with a source at or above / at or below row i
