@@ -20,29 +20,34 @@
 // Every hop lowers d by exactly the hop's L1 length, so a chain ends on a NEAREST source of its start pixel, and
 // everything that decides label(q) lies inside the L1 ball of radius d(q) around q.
 //
-// Kernels of one l1_cv pass:
+// Kernels of one l1_cv pass (seven launches):
 //   k_mask     source / value bit words + per-row prefix popcounts                    reads x once
-//   k_frame    per-frame row-count scan -> compaction ranks; frame facts; which kernel family takes the frame;
-//              value list when the source and value masks of a frame differ
-//   dense frames (every pixel within 16 of a source):
-//   k_fused<16>  one workgroup per (tile + halo 16) window, bit-sliced: the level-synchronous form of the
-//              identity on bit planes held in registers, byte codes un-sliced into LDS, lock-step chain walk,
-//              rank lookup, depth gather and the three output stores.  Hands the frame on if a tile pixel is
-//              farther than 16 from every source.
-//   every other frame (any distance, any density; dtfill_rows.hpp):
+//   k_frame    per-frame row-count scan -> compaction ranks; frame facts; the row structure (first source row, rows too far
+//              from every source row) and with it WHO takes which rows of the frame; value list when the source and value masks
+//              of a frame differ; the source list of a frame that holds a handful
+//   k_fused    dense frames (halo 16 or 32 per frame): one workgroup per (tile + halo) window, bit-sliced: the
+//              level-synchronous form of the identity on bit planes held in registers, byte codes un-sliced into LDS,
+//              lock-step chain walk, rank lookup, depth gather and the three output stores.  Hands a ROW on when one of its
+//              pixels is farther than the halo from every source.
+//              + the tiles of the frames with a handful of sources ("k_pts", dtfill_pts.hpp) in the same launch: candidates
+//              per wave box, dominance pruning, packed-key minima per pixel, k_fin's rule for the tie pixels
+//   every other frame, and the handed-on rows (any distance, any density; dtfill_rows.hpp):
 //   k_colT     per 32-row band and column: the band's source bits and the distances to the nearest source
 //              above / below the band -- everything a row needs to know about its columns; and the label of
 //              every source pixel, where k_fin can gather it
+//              + k_sky's blocks (dtfill_sky.hpp) in the same launch: the rows above the first source row (the empty sky of a
+//              LiDAR frame) in closed form from the two rows beneath
 //   k_rows     packed-key min-plus row scans: d, the nearest source (smallest and largest column that reach d:
 //              a pixel with ONE nearest source needs no chain), live; distance map + bit planes
-//   k_fin      per tile: 5x5 parent rule bit-sliced for the remaining "tie" pixels, their chains (pointer
-//              doubling in LDS), label + depth of every pixel
-//   k_tiesx    the few tie pixels whose chain crosses tiles
+//   k_fin      per tile: 5x5 parent rule bit-sliced for the remaining "tie" pixels, their chains (up to four hops through
+//              the step bytes in LDS), label + depth of every pixel
+//   k_tiesx    the few tie pixels whose chain crosses tiles or runs longer: follows the recorded links
 // l2 pass (exact Euclidean, canonical tie-break; dtfill_l2.hpp): k_mask, k_frame, then
 //   k_l2win<R> dense frames: (2R+1)^2 windows straight from the bit words, packed-key minimum over the window rows
-//   k_l2far    the odd far pixel of a dense frame, one wave each
+//   k_l2far    the odd far pixel of a dense frame, half a wave each
 //   k_colT     vertical distances per column, for sparse frames and for rows of far pixels (the empty sky)
-//   k_l2env    those rows: lower envelope of parabolas searched by monotone bisection
+//   k_l2env    sparse frames: lower envelope of parabolas searched by monotone bisection; rows of far pixels of a dense frame
+//              (the sky): a window in the column distances; frames with a handful of sources: tiles over the source list
 //
 // No MFMA anywhere: this path is compare/min/index work (DESIGN.md "Roofline").
 
@@ -353,7 +358,7 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     mark();
     {
         // the rows, one wave each; then the 32 x 32 tiles of the frames with a handful of sources, one wave each
-        const size_t wave_lds = max(l2env_lds(W), (size_t)L2_PTS_MAX * 8);
+        const size_t wave_lds = max(max(l2env_lds(W), (size_t)L2_PTS_MAX * 8), (size_t)(W + 2 * L2S_R) * 8);
         const int ntile = ((H + PT_T - 1) / PT_T) * ((W + PT_T - 1) / PT_T);
         if (4 * wave_lds <= 64 * 1024) {
             const int nrowblk = (H + 3) / 4;

@@ -15,6 +15,8 @@ constexpr int FI_SKY0 = 6;    // ... as k_frame set it.  k_fused calls the sky o
 constexpr int FI_STRIDE = 8;
 constexpr int ROUTE_POINTS = -1;  // route[b]: l2, at most L2_PTS_MAX sources in the frame (k_l2pts)
 constexpr int L2_PTS_MAX = 512;
+constexpr int W2_R16 = 10, W2_R32 = 15;  // l2: window radius of k_l2win for the frames k_frame routes 16 / 32
+constexpr u32 L2_ROW_GONE = 0x40000000u;  // l2 row flag: handed to the row search up front (above any far-pixel count's threshold)
 struct PtsSrc {  // one source of such a frame's list (k_frame writes it in raster order: index = label - 1; k_pts reads it)
     u32 rc;      // row << 16 | column
     float v;     // its depth

@@ -20,7 +20,6 @@
 // frames with route 0 are left to k_colT + k_l2env, and so are the rows of a window-kernel frame with many far pixels.
 // ------------------------------------------------------------------------------------------------
 constexpr int W2_TH = 32, W2_TW = 256;
-constexpr int W2_R16 = 10, W2_R32 = 15;  // window radius for the frames k_frame routes 16 / 32
 // a row with this many far pixels (an eighth of it: the empty sky of a LiDAR frame, not the scattered voids of a uniform one)
 // is redone whole by k_l2env instead of pixel by pixel (k_l2far)
 __device__ __forceinline__ u32 w2_row_t(int W) { return (u32)max(32, W >> 3); }
@@ -187,6 +186,15 @@ __global__ __launch_bounds__(256) void k_l2win(const float *__restrict__ x, cons
         }
         return;
     }
+    const int ty0 = blockIdx.x / tiles_x;
+    // rows k_frame (too far from every row with a source: the sky) or other blocks (too many far pixels) have handed to the
+    // row search: nothing of them is computed, stored or counted here; a tile that holds no other row is done
+    u64 rowgone = 0ull;
+    if (fflag2[b]) {  // (block-uniform; a frame without such rows does not pay for the look)
+        const int l = threadIdx.x & 63, row = ty0 * W2_TH + l;
+        rowgone = __ballot(l < W2_TH && (row >= H || rowfar[(size_t)b * H + min(row, H - 1)] >= w2_row_t(W)));
+        if ((u32)rowgone == 0xFFFFFFFFu) return;  // block-uniform: every wave computes the same mask
+    }
     entry_t *s_h = reinterpret_cast<entry_t *>(lds);
     uint4 *s_x = reinterpret_cast<uint4 *>(lds + C::OFF_X);
     u64 *s_w = reinterpret_cast<u64 *>(lds + C::OFF_W);
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256) void k_l2win(const float *__restrict__ x, cons
                 m = min3u(m, (e[u + dyi] << DB) + (u32)(((dyi - R) * (dyi - R)) << DB | dyi),
                           (e[u + dyi + 1] << DB) + (u32)(((dyi + 1 - R) * (dyi + 1 - R)) << DB | (dyi + 1)));
             best[u] = min(m, (e[u + 2 * R] << DB) + (u32)((R * R) << DB | (2 * R)));
-            far[u] = inw & (y0 + t0 + u < H) & ((best[u] >> DB) > (u32)(R * R));
+            far[u] = inw & (y0 + t0 + u < H) & ((best[u] >> DB) > (u32)(R * R)) & !((rowgone >> (t0 + u)) & 1ull);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // a pixel with no source within R: counted per row; a few go on k_l2far's list, 32 or more of
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void k_l2win(const float *__restrict__ x, cons
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = y0 + t0 + u;
-            S.live[u] = inw & (i < H) & !far[u];
+            S.live[u] = inw & (i < H) & !far[u] & !((rowgone >> (t0 + u)) & 1ull);
             const u32 d2 = min(best[u] >> DB, (u32)(R * R));  // clamped for the table (a far pixel stores nothing)
             const int dyi = (int)(best[u] & ((1u << DB) - 1u)), dy = dyi - R;
             const int dx2 = max((int)d2 - dy * dy, 0);
@@ -537,6 +545,128 @@ __device__ __forceinline__ void l2env_row(const float *__restrict__ x, const uin
 }
 
 // ------------------------------------------------------------------------------------------------
+// A row of far pixels of a window-kernel frame -- the empty sky of a LiDAR frame: every column has its source a long way down,
+// the nearest of them all differ little.  There the owner of pixel j is a column NEAR j, and the search over the lower
+// envelope (above: a few thousand instructions of bookkeeping per row) is replaced by a window in the COLUMN distances:
+//     best(j) = min over |k - j| <= R of g(k)^2 + (j - k)^2,
+// exact as soon as best(j) < gmin^2 + (R + 1)^2 (gmin = the row's smallest column distance: no column outside the window can
+// do better, or as well).  R starts at L2S_R and grows by L2S_R for the pixels that fail the test (none to speak of on a sky
+// over ring rows); a window that has grown over the whole row is exact by exhaustion.  Keys compare as (d2, source row,
+// column): ties go to the smallest raster index of the source, as brute force gives.  One wave per row; the columns' {g^2,
+// source row << 16 | column} are staged in LDS with a margin of "no column" on either side.
+// ------------------------------------------------------------------------------------------------
+constexpr int L2S_R = 16;
+__device__ __forceinline__ void l2sky_row(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
+                                          const int32_t *__restrict__ labelmap, const int *__restrict__ finfo,
+                                          const float *__restrict__ vlist, int H, int W, int b, int i, float *__restrict__ out_depth,
+                                          float *__restrict__ out_dt, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
+                                          unsigned char *s_env) {
+    uint2 *s_col = reinterpret_cast<uint2 *>(s_env) + L2S_R;  // [-L2S_R, W + L2S_R): {g^2, source row << 16 | column}; 0x7FFFFFFF: no source / outside the row
+    const int lane = threadIdx.x & 63;
+    const size_t fo = (size_t)b * H * W;
+    u32 gmin = 0xFFFFFFFFu;
+    {
+        const int band = i >> 5, r = i & 31;
+        const uint2 *crow = ct + ((size_t)b * nb + band) * CTP;
+        const u32 upmask = (2u << r) - 1u;
+        if (lane < 2 * L2S_R) s_col[lane < L2S_R ? lane - L2S_R : W + lane - L2S_R] = make_uint2(0x7FFFFFFFu, 0xFFFFFFFFu);
+        for (int k = lane; k < W; k += 64) {
+            const uint2 w = crow[k];
+            const u32 gu = min(ffbh_u32(w.x & upmask) + (u32)(r - 31), (w.y & 0xFFFFu) + (u32)r);
+            const u32 gd = min(ffbl_b32(w.x >> r), (w.y >> 16) + (u32)(31 - r));
+            const u32 m = min(gu, gd);  // on a vertical tie the upper source (the smaller raster index)
+            const bool has = m < (u32)MAX_HW_SUM;
+            s_col[k] = make_uint2(has ? m * m : 0x7FFFFFFFu, (u32)(gd < gu ? i + (int)m : i - (int)m) << 16 | (u32)k);
+            gmin = min(gmin, has ? m : 0xFFFFFFFFu);
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) gmin = min(gmin, (u32)__shfl_xor((int)gmin, o));
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
+    const float *gsrc = misaligned ? vlist + fo : x + fo;
+    const bool any = gmin != 0xFFFFFFFFu;  // the frame has a source at all (a routed frame does)
+    const u32 gmin2 = any ? gmin * gmin : 0u;
+    bool index_error = false;
+    auto search = [&](int j) -> unsigned long long {
+        const bool in = j < W;
+        unsigned long long best = ~0ull;
+        // first the 2 L2S_R + 1 columns around the pixel, all lanes together, no bounds (the margins hold "no column": a key
+        // that loses against every real one); 0x7FFFFFFF + (j - k)^2 stays below 2^32
+        const int jc = min(j, W - 1);
+        uint2 cv[2 * L2S_R + 1];
+#pragma unroll
+        for (int t = 0; t <= 2 * L2S_R; ++t) cv[t] = s_col[jc - L2S_R + t];
+#pragma unroll
+        for (int t = 0; t <= 2 * L2S_R; ++t) {
+            const unsigned long long key = (unsigned long long)(cv[t].x + (u32)((t - L2S_R) * (t - L2S_R))) << 32 | cv[t].y;
+            best = key < best ? key : best;
+        }
+        // then, for the pixels that are not sure yet, ring by ring; a lane that has its answer (or has seen the whole row)
+        // stops taking part
+        int R = L2S_R;
+        bool open = in && (u32)(best >> 32) >= gmin2 + (u32)((R + 1) * (R + 1)) && (j - R > 0 || j + R < W - 1);
+        while (__any(open)) {
+            if (open) {
+                for (int k = max(j - R - L2S_R, 0); k <= min(j - R - 1, W - 1); ++k) {
+                    const uint2 c2 = s_col[k];
+                    const unsigned long long key = (unsigned long long)(c2.x + (u32)((j - k) * (j - k))) << 32 | c2.y;
+                    best = key < best ? key : best;
+                }
+                for (int k = max(j + R + 1, 0); k <= min(j + R + L2S_R, W - 1); ++k) {
+                    const uint2 c2 = s_col[k];
+                    const unsigned long long key = (unsigned long long)(c2.x + (u32)((j - k) * (j - k))) << 32 | c2.y;
+                    best = key < best ? key : best;
+                }
+                R += L2S_R;
+                open = (u32)(best >> 32) >= gmin2 + (u32)((R + 1) * (R + 1)) && (j - R > 0 || j + R < W - 1);
+            }
+        }
+        return best;
+    };
+    // four groups of 64 pixels per step: their label and depth gathers are in flight together
+    for (int j0 = 0; j0 < W; j0 += 256) {
+        unsigned long long best[4];
+        int q[4], label[4];
+        float dep[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 64 * u + lane;
+            in[u] = j < W;
+            best[u] = (any && j0 + 64 * u < W) ? search(j) : ~0ull;  // (the group test is wave-uniform)
+            q[u] = any ? (int)((u32)best[u] >> 16) * W + (int)((u32)best[u] & 0xFFFFu) : 0;
+            label[u] = 0;
+            dep[u] = 0.0f;
+        }
+        if (any && (out_index || out_depth)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (in[u]) label[u] = labelmap[fo + q[u]];  // k_colT wrote the sources' labels
+        }
+        if (out_depth) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // depth_list[label - 1] with numpy's index semantics (tools.py:26)
+                int idx = label[u] - 1;
+                if (idx < 0) idx += nval;
+                const bool ok = idx >= 0 && idx < nval;
+                dep[u] = (in[u] && ok) ? gsrc[misaligned ? idx : q[u]] : nanf("");
+                index_error |= in[u] && !ok;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!in[u]) continue;
+            const size_t o = fo + (size_t)i * W + j0 + 64 * u + lane;
+            if (out_index) __builtin_nontemporal_store((int32_t)label[u], &out_index[o]);
+            if (out_dt) __builtin_nontemporal_store(any ? sqrtf((float)(u32)(best[u] >> 32)) : INFINITY, &out_dt[o]);
+            if (out_depth) __builtin_nontemporal_store(dep[u], &out_depth[o]);
+        }
+    }
+    if (out_depth && index_error) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_l2far: the far list of the window-kernel frames (l2far_list), one wave per listed pixel.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_l2far(const float *__restrict__ x, const u64 *__restrict__ srcbits,
@@ -677,6 +807,9 @@ __global__ __launch_bounds__(64 * WPB, 5) void k_l2env(const float *__restrict__
         return;
     }
     const int i = (int)blockIdx.x * WPB + wv;
-    if (i < H && (r == 0 || (r > 0 && rowfar[(size_t)b * H + i] >= w2_row_t(W))))
+    if (i >= H) return;
+    if (r == 0)  // a sparse frame: few columns hold a source, the distances are large -- the envelope search
         l2env_row<1>(x, ct, CTP, nb, labelmap, finfo, vlist, H, W, b, i, out_depth, out_dt, out_index, frame_status, lds, nullptr);
+    else if (r > 0 && rowfar[(size_t)b * H + i] >= w2_row_t(W))  // a row of far pixels of a dense frame (the sky): the window in column distances
+        l2sky_row(x, ct, CTP, nb, labelmap, finfo, vlist, H, W, b, i, out_depth, out_dt, out_index, frame_status, lds);
 }

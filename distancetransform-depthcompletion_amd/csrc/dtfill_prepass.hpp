@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
                 vd = min(up, dn);
                 dlb = max(dlb, vd);
             }
-            const u64 f16 = __ballot(i < H && i >= r0 && vd > PM16), f32 = __ballot(i < H && i >= r0 && vd > PM32);
+            // l2: the rows farther from every row with a source than the window kernel's radius (no pixel of them has a source in its window)
+            const u64 f16 = __ballot(i < H && (l2 ? vd > W2_R16 : (i >= r0 && vd > PM16))), f32 = __ballot(i < H && (l2 ? vd > W2_R32 : (i >= r0 && vd > PM32)));
             if (lane == 0 && i < Hp) {
                 s_far[0][i >> 5] = (u32)f16;
                 s_far[0][(i >> 5) + 1] = (u32)(f16 >> 32);
@@ -469,10 +470,12 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     for (int i = tid; i < H; i += 256) {
         u32 f = 0u;
         if (flags && r > 0) f = i < r0 && sky_ok ? (sky ? 2u : 1u) : (far[i >> 5] >> (i & 31)) & 1u;
+        if (l2 && r > 0 && ((far[i >> 5] >> (i & 31)) & 1u)) f = L2_ROW_GONE;  // (a frame without sources is not routed to a window)
         one |= f == 1u;
         rowfar[(size_t)b * H + i] = f;
     }
     const bool any1 = __syncthreads_or(one);
+    const bool anygone = l2 && r > 0 && s_nfar[r == 32 ? 1 : 0] > 0;  // l2: rows for k_colT + k_l2env from the start
     if (tid == 0) {
         finfo[b * FI_STRIDE + FI_NSRC] = (int)run_s;
         finfo[b * FI_STRIDE + FI_NVAL] = (int)run_v;
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         // 2: the any-distance kernels take the whole frame; 1: the rows flagged 1 (pre-marked here, or by k_fused, or (l2) by
         // k_l2win when it hands a row of far pixels on); 0: nothing for them
         // 3 (l1_cv, ROUTE_POINTS): k_pts takes the frame, of the any-distance kernels only k_tiesx has something to do
-        fflag2[b] = (!l2 && r == ROUTE_POINTS) ? 3 : general ? 2 : (flags && any1) ? 1 : 0;
+        fflag2[b] = (!l2 && r == ROUTE_POINTS) ? 3 : general ? 2 : ((flags && any1) || anygone) ? 1 : 0;
         frame_status[b] = (general || r == ROUTE_POINTS || marked) ? DTFILL_FRAME_GENERAL_PATH : DTFILL_FRAME_OK;
     }
     if (misaligned) {

@@ -1,4 +1,4 @@
-// dtfill_rows.hpp -- k_colT, k_rows, k_ties, k_tiesx: the any-distance path of the l1_cv pass (argmin scans)
+// dtfill_rows.hpp -- k_colT, k_rows, k_fin, k_tiesx: the any-distance path of the l1_cv pass (argmin scans)
 // Part of libdtfill.so; included by dtfill.hip inside its anonymous namespace (one translation unit).
 #pragma once
 
@@ -15,16 +15,23 @@
 // Only "tie" pixels (3 % - 22 % on the bench workloads) apply the 5x5 parent rule, and they hop only
 // until they stand on a pixel with one nearest source (1.0 - 1.6 hops on average).
 //
+// Which rows: all of a frame k_frame routes here (fflag 2), or the rows flagged 1 of a window-kernel frame (fflag 1: rows
+// too far from every source row, marked by k_frame up front; rows in which k_fused met a pixel beyond its halo; the sky's
+// rows when k_fused had to call k_sky off).  A frame of k_pts (fflag 3) only passes through k_tiesx.
+//
 //   k_colT   srcbits -> per 32-row band and column: the band's source bits of that column (one word) and
-//            the distance from the band's first / last row to the nearest source above / below the band.
-//            0.25 B/px; everything a row needs to know about its columns.
+//            the distance from the band's first / last row to the nearest source above / below the band:
+//            0.25 B/px, everything a row needs to know about its columns; the label of every source pixel (labelmap).
+//            k_sky's blocks (dtfill_sky.hpp) ride behind the column blocks of this launch.
 //   k_rows   one block per image row: column distances from the band words, six packed-key scans
-//            (kmin / kmax / upper-sources, left and right), d, the nearest source, label, depth gather,
-//            the three output stores; five bit planes (d mod 8, live, tie) for k_ties.
-//   k_ties   one block per 64 x 128 tile: bit-sliced 5x5 parent rule on the planes, tie pixels hop through
-//            the tile's window in LDS and copy label + depth of the pixel they end on.
-//   k_tiesx  the few tie pixels whose hops left the window: the same rule, evaluated per hop from the
-//            planes in global memory (any chain length).
+//            (kmin / kmax / upper-sources, left and right): d, the nearest source in column kmin (spix), "one nearest
+//            source", live; stores the distance map, spix, and five bit planes (d mod 8, live, tie) for k_fin.
+//   k_fin    one block per 32 x 256 tile: bit-sliced 5x5 parent rule on the planes for the words that hold a tie pixel,
+//            step bytes, up to Q_HOPS hops per tie pixel inside the tile; every pixel takes the source of the pixel that ends
+//            its chain; label (labelmap gather) and depth (gather) of every pixel, written once as whole lines.  A chain
+//            that leaves the tile on tie pixels, or is longer, is listed for k_tiesx with the pixel where it goes on.
+//   k_tiesx  the listed pixels: follows the recorded links (one memory round trip per link, whatever the chain's length
+//            inside the tiles) to a finished pixel and copies its label and depth.
 // ================================================================================================
 
 constexpr int GBIG = 16383;  // column distance when the column has no source (d >= 8192 <=> frame without sources)
