@@ -94,7 +94,7 @@ struct Carve {
     u32 *xlist, *xptr;   // k_fin -> k_tiesx: the pixels whose chain left their tile, and where each goes on
     float *dscratch;     // k_fin -> k_tiesx: depths of the rows a depth epilogue drops from the output
     u32 *spix;           // k_rows -> k_fin: per pixel, the frame offset of its nearest source in column kmin
-    int32_t *labelmap;   // k_labels: at every source pixel, its label (1 + raster rank among the frame's sources)
+    uint4 *rec;          // k_colT -> k_fin, k_l2env: rank records, per 64-pixel word of a row (label_from_rec)
     int *finfo, *fflag2, *route, *status, *negflag;
     float *vlist;
     PtsSrc *ptslist;     // k_frame -> k_pts: the sources of a frame that has a handful (l1_cv, ROUTE_POINTS)
@@ -132,7 +132,7 @@ Carve carve(void *ws, int B, int H, int W) {
     c.nb = (H + 31) / 32;
     c.ctp = ct_pitch(W);
     c.ct = (uint2 *)take((size_t)B * c.nb * c.ctp * sizeof(uint2));
-    c.labelmap = (int32_t *)take(N * 4);
+    c.rec = (uint4 *)take(NW * sizeof(uint4));
     c.spix = (u32 *)take(N * 4);
     c.dscratch = (float *)take(N * 4);
     c.xlist = (u32 *)take(N * 4);
@@ -255,16 +255,20 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         // k_sky's blocks (the rows above the first source row, dtfill_sky.hpp) ride behind the column blocks
         SkyArgs sky = {c.finfo, out_dt, out_dt_caller, out_depth, out_index, (W + SKY_SW - 1) / SKY_SW, 0};
         size_t lds = colT_lds(nb);
-        if (rowflags) {
+        const bool sky_rides = rowflags && cw <= SKY_NT / 64;  // (taller frames: a launch of its own, below)
+        if (sky_rides) {
             sky.nblocks = sky.nstrips * ((H + SKY_RG - 1) / SKY_RG);
-            cw = max(cw, SKY_NT / 64);
+            cw = SKY_NT / 64;
             lds = max(lds, sky_lds(sky_span_max(H, W)));
         }
         if (lds > 48 * 1024)  // (set per call: the attribute belongs to the current device)
             ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_colT), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         const int ncol = (c.ctp + 63) / 64;
         k_colT<<<dim3(ncol + sky.nblocks, B), 64 * cw, lds, st>>>(c.srcbits, c.fflag2, H, W, Wd, nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s,
-                                                             (out_depth || out_index) ? c.labelmap : nullptr, ncol, sky);
+                                                             (out_depth || out_index) ? c.rec : nullptr, ncol, sky);
+        if (rowflags && !sky_rides)
+            k_sky<<<dim3(sky.nstrips * ((H + SKY_RG - 1) / SKY_RG), B), SKY_NT, sky_lds(sky_span_max(H, W)), st>>>(
+                c.finfo, H, W, out_dt, out_dt_caller, out_depth, out_index, sky.nstrips);
         mark();
         const int Wp = Wd * 8;
         // columns per lane: 8 or 10, whichever leaves fewer idle lanes in the row's last wave
@@ -295,7 +299,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         if (fin) {
             const int ttx = (W + Q_TW - 1) / Q_TW, tty = (H + Q_TH - 1) / Q_TH;
             const int vec = (W & 3) == 0 && aligned(out_depth, 16) && aligned(out_index, 16);
-            k_fin<<<dim3(ttx * tty, B), Q_NT, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, Wd, ttx, c.spix, x, c.labelmap,
+            k_fin<<<dim3(ttx * tty, B), Q_NT, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, Wd, ttx, c.spix, x, c.rec,
                                                        c.vlist, out_depth, out_index, status, c.finfo,
                                                        c.xlist, c.xptr, c.planes + PL_UNRES * c.plane_bytes, vec, ep, c.dscratch, c.rowfar);
             mark();
@@ -353,7 +357,7 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         if (lds > 48 * 1024)
             ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_colT), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, lds, st>>>(c.srcbits, c.fflag2, H, W, Wd, c.nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s,
-                                                         (out_depth || out_index) ? c.labelmap : nullptr, (c.ctp + 63) / 64, SkyArgs{});
+                                                         (out_depth || out_index) ? c.rec : nullptr, (c.ctp + 63) / 64, SkyArgs{});
     }
     mark();
     {
@@ -362,14 +366,14 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const int ntile = ((H + PT_T - 1) / PT_T) * ((W + PT_T - 1) / PT_T);
         if (4 * wave_lds <= 64 * 1024) {
             const int nrowblk = (H + 3) / 4;
-            k_l2env<4><<<dim3(nrowblk + (ntile + 3) / 4, B), 256, 4 * wave_lds, st>>>(x, c.ct, c.ctp, c.nb, c.labelmap, c.finfo, c.vlist, c.route,
+            k_l2env<4><<<dim3(nrowblk + (ntile + 3) / 4, B), 256, 4 * wave_lds, st>>>(x, c.ct, c.ctp, c.nb, c.rec, Wd, c.finfo, c.vlist, c.route,
                                                                                   c.rowfar, c.xlist, H, W, nrowblk, wave_lds, 1, out_depth,
                                                                                   out_dt, out_index, status);
         } else {
             if (wave_lds > 48 * 1024)  // rows wider than ~4900 pixels (set per call: the attribute belongs to the current device)
                 ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_l2env<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)l2env_lds(8192)) == hipSuccess;
-            k_l2env<1><<<dim3(H + (ntile + 7) / 8, B), 64, wave_lds, st>>>(x, c.ct, c.ctp, c.nb, c.labelmap, c.finfo, c.vlist, c.route, c.rowfar, c.xlist,
+            k_l2env<1><<<dim3(H + (ntile + 7) / 8, B), 64, wave_lds, st>>>(x, c.ct, c.ctp, c.nb, c.rec, Wd, c.finfo, c.vlist, c.route, c.rowfar, c.xlist,
                                                                H, W, H, wave_lds, 8, out_depth, out_dt, out_index, status);
         }
     }

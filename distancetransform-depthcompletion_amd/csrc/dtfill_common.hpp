@@ -71,3 +71,11 @@ __device__ __forceinline__ u32 *rowflag_of(int *fflag, int B) {
 
 // row flag f of a frame whose sky is / is not k_sky's: is the row one of the any-distance kernels'?
 __device__ __forceinline__ bool row_is_anydist(u32 f, int sky_live) { return f == 1u || (f == 2u && !sky_live); }
+
+// Rank records (k_colT -> k_fin, k_l2env): per 64-pixel word of a row {low 32 source bits, sources before them in the frame,
+// high 32 bits, sources before those}; records of one word column are consecutive in the row index.  The label of the source
+// at (si, sj) = 1 + its raster rank among the frame's sources (cv2's label init) = one 8-byte read + a popcount.
+__device__ __forceinline__ int label_from_rec(const uint2 *__restrict__ rec_f /* the frame's records */, int H, int si, int sj) {
+    const uint2 r = rec_f[(((size_t)(sj >> 6) * H + si) << 1) + ((sj >> 5) & 1)];
+    return (int)r.y + __popc(r.x & ((1u << (sj & 31)) - 1u)) + 1;
+}

@@ -416,7 +416,7 @@ __device__ __forceinline__ void l2env_sync() {
 }
 template <int NW>
 __device__ __forceinline__ void l2env_row(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
-                                          const int32_t *__restrict__ labelmap, const int *__restrict__ finfo,
+                                          const uint4 *__restrict__ rec, int Wd, const int *__restrict__ finfo,
                                           const float *__restrict__ vlist, int H, int W, int b, int i,
                                           float *__restrict__ out_depth, float *__restrict__ out_dt,
                                           int32_t *__restrict__ out_index, int *__restrict__ frame_status,
@@ -500,11 +500,12 @@ __device__ __forceinline__ void l2env_row(const float *__restrict__ x, const uin
     const float *gsrc = misaligned ? vlist + fo : x + fo;
     bool index_error = false;
     for (int j0 = 0; j0 < W; j0 += 4 * NT) {  // four pixels per lane and step: their gathers are in flight together
-        int q[4], label[4];
+        int q[4], label[4], sr[4], sc[4];
         float dist[4], dep[4];
         bool in[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            sr[u] = sc[u] = 0;
             const int j = j0 + NT * u + tid;
             in[u] = j < W;
             q[u] = i * W + min(j, W - 1);
@@ -514,12 +515,14 @@ __device__ __forceinline__ void l2env_row(const float *__restrict__ x, const uin
                 const uint2 cv = s_c[s_own[min(j, W - 1)]];
                 const int scol = (int)(cv.y & 0xFFFFu), dk = min(j, W - 1) - scol;
                 q[u] = (int)(cv.y >> 16) * W + scol;
+                sr[u] = (int)(cv.y >> 16);
+                sc[u] = scol;
                 dist[u] = sqrtf((float)(cv.x + (u32)(dk * dk)));
             }
         }
         if (c > 0 && (out_index || out_depth)) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) label[u] = labelmap[fo + q[u]];  // k_colT wrote the sources' labels
+            for (int u = 0; u < 4; ++u) label[u] = label_from_rec(reinterpret_cast<const uint2 *>(rec + (size_t)b * Wd * H), H, sr[u], sc[u]);  // k_colT wrote the rank records
         }
         if (out_depth) {
 #pragma unroll
@@ -557,7 +560,7 @@ __device__ __forceinline__ void l2env_row(const float *__restrict__ x, const uin
 // ------------------------------------------------------------------------------------------------
 constexpr int L2S_R = 16;
 __device__ __forceinline__ void l2sky_row(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
-                                          const int32_t *__restrict__ labelmap, const int *__restrict__ finfo,
+                                          const uint4 *__restrict__ rec, int Wd, const int *__restrict__ finfo,
                                           const float *__restrict__ vlist, int H, int W, int b, int i, float *__restrict__ out_depth,
                                           float *__restrict__ out_dt, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
                                           unsigned char *s_env) {
@@ -642,7 +645,7 @@ __device__ __forceinline__ void l2sky_row(const float *__restrict__ x, const uin
         if (any && (out_index || out_depth)) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (in[u]) label[u] = labelmap[fo + q[u]];  // k_colT wrote the sources' labels
+                if (in[u]) label[u] = label_from_rec(reinterpret_cast<const uint2 *>(rec + (size_t)b * Wd * H), H, (int)((u32)best[u] >> 16), (int)((u32)best[u] & 0xFFFFu));  // k_colT wrote the rank records
         }
         if (out_depth) {
 #pragma unroll
@@ -786,7 +789,7 @@ __device__ __forceinline__ void l2pts_tile(const float *__restrict__ x, const u3
 // ------------------------------------------------------------------------------------------------
 template <int WPB>  // waves per block, each on a unit of its own: 4 while four rows' LDS fit 64 KB (W <= 1638), else 1
 __global__ __launch_bounds__(64 * WPB, 5) void k_l2env(const float *__restrict__ x, const uint2 *__restrict__ ct, int CTP, int nb,
-                                                    const int32_t *__restrict__ labelmap, const int *__restrict__ finfo,
+                                                    const uint4 *__restrict__ rec, int Wd, const int *__restrict__ finfo,
                                                     const float *__restrict__ vlist, const int *__restrict__ route,
                                                     const u32 *__restrict__ rowfar, const u32 *__restrict__ srclist, int H, int W,
                                                     int nrowblk, size_t wave_lds, int tpw, float *__restrict__ out_depth,
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void k_l2env(const float *__restrict__
     const int i = (int)blockIdx.x * WPB + wv;
     if (i >= H) return;
     if (r == 0)  // a sparse frame: few columns hold a source, the distances are large -- the envelope search
-        l2env_row<1>(x, ct, CTP, nb, labelmap, finfo, vlist, H, W, b, i, out_depth, out_dt, out_index, frame_status, lds, nullptr);
+        l2env_row<1>(x, ct, CTP, nb, rec, Wd, finfo, vlist, H, W, b, i, out_depth, out_dt, out_index, frame_status, lds, nullptr);
     else if (r > 0 && rowfar[(size_t)b * H + i] >= w2_row_t(W))  // a row of far pixels of a dense frame (the sky): the window in column distances
-        l2sky_row(x, ct, CTP, nb, labelmap, finfo, vlist, H, W, b, i, out_depth, out_dt, out_index, frame_status, lds);
+        l2sky_row(x, ct, CTP, nb, rec, Wd, finfo, vlist, H, W, b, i, out_depth, out_dt, out_index, frame_status, lds);
 }

@@ -21,14 +21,14 @@
 //
 //   k_colT   srcbits -> per 32-row band and column: the band's source bits of that column (one word) and
 //            the distance from the band's first / last row to the nearest source above / below the band:
-//            0.25 B/px, everything a row needs to know about its columns; the label of every source pixel (labelmap).
+//            0.25 B/px, everything a row needs to know about its columns; and the rank records (label_from_rec) k_fin turns a source into its label with.
 //            k_sky's blocks (dtfill_sky.hpp) ride behind the column blocks of this launch.
 //   k_rows   one block per image row: column distances from the band words, six packed-key scans
 //            (kmin / kmax / upper-sources, left and right): d, the nearest source in column kmin (spix), "one nearest
 //            source", live; stores the distance map, spix, and five bit planes (d mod 8, live, tie) for k_fin.
 //   k_fin    one block per 32 x 256 tile: bit-sliced 5x5 parent rule on the planes for the words that hold a tie pixel,
 //            step bytes, up to Q_HOPS hops per tie pixel inside the tile; every pixel takes the source of the pixel that ends
-//            its chain; label (labelmap gather) and depth (gather) of every pixel, written once as whole lines.  A chain
+//            its chain; label (rank record + popcount) and depth (gather) of every pixel, written once as whole lines.  A chain
 //            that leaves the tile on tie pixels, or is longer, is listed for k_tiesx with the pixel where it goes on.
 //   k_tiesx  the listed pixels: follows the recorded links (one memory round trip per link, whatever the chain's length
 //            inside the tiles) to a finished pixel and copies its label and depth.
@@ -56,7 +56,7 @@ __host__ __device__ inline size_t colT_lds(int nb) { return (size_t)nb * 64 * (2
 __device__ __forceinline__ void colT_block(const u64 *__restrict__ srcbits, const int *__restrict__ fflag, int H,
                                            int W, int Wd, int nb, int CTP, uint2 *__restrict__ ct,
                                            const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
-                                           int32_t *__restrict__ labelmap, int wd, u16 *s_lf, u64 (*s_rowword)[64]) {
+                                           uint4 *__restrict__ rec, int wd, u16 *s_lf, u64 (*s_rowword)[64]) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
     if (fflag && (!fflag[b] || fflag[b] == 3)) return;  // 3: k_pts's frame
@@ -75,7 +75,7 @@ __device__ __forceinline__ void colT_block(const u64 *__restrict__ srcbits, cons
         if (real && row < H) {
             const size_t wi = ((size_t)b * H + row) * Wd + wd;
             w = srcbits[wi];
-            if (labelmap) base = rowbase_s[(size_t)b * H + row] + wpre_s[wi];
+            if (rec) base = rowbase_s[(size_t)b * H + row] + wpre_s[wi];
         }
         // transpose the 64 x 64 bits through LDS: every lane reads the 64 row words (one broadcast read each) and keeps
         // its column's bit of each -- lane = column afterwards
@@ -86,18 +86,9 @@ __device__ __forceinline__ void colT_block(const u64 *__restrict__ srcbits, cons
             t_lo |= (u32)((s_rowword[ch][rr] >> lane) & 1ull) << rr;
             t_hi |= (u32)((s_rowword[ch][rr + 32] >> lane) & 1ull) << rr;
         }
-        if (labelmap && w) {
-            // label of every source pixel of this row: 1 + raster rank among the frame's sources (cv2's label init:
-            // k = 1; every zero pixel of the mask gets k++) = sources in the rows before + in the words before + before
-            // it in the word.  Only source pixels are written (and only those are ever read).
-            int32_t *lrow = labelmap + ((size_t)b * H + row) * W + wd * 64;
-            u64 m = w;
-            u32 lab = base;
-            while (m) {
-                const int k = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                lrow[k] = (int32_t)++lab;
-            }
+        if (rec && real && row < H) {
+            // the rank record of this row's word (common.hpp: label_from_rec): lanes = consecutive rows -> one 1 KB run per store
+            rec[((size_t)b * Wd + wd) * H + row] = make_uint4((u32)w, base, (u32)(w >> 32), base + (u32)__popc((u32)w));
         }
         if (keep_t) {  // the bits wait in LDS for their {up, down}: one 8-byte store per element at the end
             s_t[band * 64 + lane] = t_lo;
@@ -160,7 +151,7 @@ __device__ __forceinline__ void sky_body(unsigned char *s_sky, const int *__rest
 __global__ __launch_bounds__(1024) void k_colT(const u64 *__restrict__ srcbits, const int *__restrict__ fflag, int H,
                                                int W, int Wd, int nb, int CTP, uint2 *__restrict__ ct,
                                                const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
-                                               int32_t *__restrict__ labelmap, int ncolblocks, const SkyArgs sky) {
+                                               uint4 *__restrict__ rec, int ncolblocks, const SkyArgs sky) {
     extern __shared__ __attribute__((aligned(16))) u16 s_lf[];
     __shared__ u64 s_rowword[16][64];
     if ((int)blockIdx.x >= ncolblocks) {  // (block-uniform)
@@ -169,7 +160,7 @@ __global__ __launch_bounds__(1024) void k_colT(const u64 *__restrict__ srcbits, 
                  k / sky.nstrips);
         return;
     }
-    colT_block(srcbits, fflag, H, W, Wd, nb, CTP, ct, wpre_s, rowbase_s, labelmap, (int)blockIdx.x, s_lf, s_rowword);
+    colT_block(srcbits, fflag, H, W, Wd, nb, CTP, ct, wpre_s, rowbase_s, rec, (int)blockIdx.x, s_lf, s_rowword);
 }
 
 __device__ __forceinline__ u32 ffbh_u32(u32 v) {  // position of the highest set bit from the top; 0xFFFFFFFF for 0
@@ -391,7 +382,7 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
 
     // ---- per pixel: distance, nearest source, flags
     float fd[PPL];
-    u32 spix[PPL];  // frame offset of the nearest source in column kmin; SPIX_NONE: the frame has no source
+    u32 spix[PPL];  // the nearest source in column kmin as row << 16 | column; SPIX_NONE: the frame has no source
     u32 acc012 = 0, acc34 = 0;  // bit planes of the lane's pixels: plane p of pixel q at bit 10 p + q
     const u32 jbase = ((u32)idx0 << K_SH) - ((u32)K_OFF << K_SH);
 #pragma unroll
@@ -421,7 +412,7 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
         const int sg = (int)((bmin & 1u) << 1) - 1;                              // below: +1, above: -1
         const int si = min(max(i + sg * gk, 0), H - 1);  // clamps: never taken on a correct frame
         const u32 sj = min(kmin, (u32)(W - 1));
-        spix[q] = none ? SPIX_NONE : (u32)si * (u32)W + sj;  // frame offset of the source pixel
+        spix[q] = none ? SPIX_NONE : (u32)si << 16 | sj;  // the source pixel: row << 16 | column
     }
     // ---- bit planes: a lane's PPL bits of each plane are ORed into the row's words in LDS
     if (idx0 < W) {
@@ -554,7 +545,7 @@ __device__ __forceinline__ void step_tap(const u32 (&C)[4], u32 mytie, u32 (&E)[
 
 __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     const u8 *__restrict__ planes, size_t plane_bytes, int Wp, const int *__restrict__ fflag, int H, int W, int Wd,
-    int tiles_x, const u32 *__restrict__ spix_ws, const float *__restrict__ x, const int32_t *__restrict__ labelmap,
+    int tiles_x, const u32 *__restrict__ spix_ws, const float *__restrict__ x, const uint4 *__restrict__ rec,
     const float *__restrict__ vlist,
     float *__restrict__ out_depth, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
     int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres, int vec,
@@ -697,14 +688,13 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     // ---- 4. label, depth, stores.  A wave takes tile rows ewave, ewave + waves, ...; a lane four consecutive pixels.
     const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
     const float *x_f = x + fo, *vl_f = vlist + fo;
-    const int32_t *lm_f = labelmap + fo;
+    const uint2 *rec_f = reinterpret_cast<const uint2 *>(rec + (size_t)b * Wd * H);
     // the depth output may drop the first ep.row0 rows (frames are then H - row0 rows apart); the depths of the dropped
     // rows go to a scratch frame instead, where k_tiesx finds them if a handed-on chain ends there
     float *dp_f = out_depth ? out_depth + (size_t)b * (H - ep.row0) * W : nullptr;
     float *ds_f = dscratch + fo;
     const u32 dcrop = (u32)(ep.row0 * W) << 2;
     int32_t *ix_f = out_index ? out_index + fo : nullptr;
-    const u32 lastpix = (u32)(H * W - 1);
     bool bad = false;
     constexpr int NRW = Q_TH / (Q_NT / 64);  // rows per wave (8)
     // Every pixel takes the source k_rows found for the pixel that ends its chain: itself unless it is a tie pixel; a tie
@@ -782,7 +772,7 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
         }
     }
     if (tin) reinterpret_cast<u32 *>(unres + (rowb + gi) * Wp)[gw] = s_unres[tid];
-    // label = labelmap[source], depth = depth_list[label - 1] = x[source] when the masks agree: two gathers per pixel,
+    // label from the source's rank record, depth = depth_list[label - 1] = x[source] when the masks agree: two gathers per pixel,
     // all 32 pixels of the lane in flight together
     int lab[NRW][4];
     float val[NRW][4];
@@ -794,9 +784,10 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
             const u32 v = esp[it][u];
             const bool none = v == SPIX_NONE;
             nonem |= none ? 1u << (4 * it + u) : 0u;
-            const u32 off = (none ? 0u : min(v, lastpix)) << 2;
-            lab[it][u] = ix_f || misaligned ? ld_off<int32_t>(lm_f, off) : 0;
-            val[it][u] = dp_f ? ld_off<float>(x_f, off) : 0.0f;
+            // v = source row << 16 | column (the clamps only make sure that a logic error could never become a wild access)
+            const int si = none ? 0 : min((int)(v >> 16), H - 1), sj = none ? 0 : min((int)(v & 0xFFFFu), W - 1);
+            lab[it][u] = ix_f || misaligned ? label_from_rec(rec_f, H, si, sj) : 0;
+            val[it][u] = dp_f ? ld_off<float>(x_f, (u32)(__umul24((u32)si, (u32)W) + (u32)sj) << 2) : 0.0f;
         }
 #pragma unroll
     for (int it = 0; it < NRW; ++it) {

@@ -94,3 +94,11 @@ __device__ __forceinline__ void sky_body(unsigned char *s_sky, const int *__rest
         if (out_depth) __builtin_nontemporal_store(__uint_as_float(v.y), &out_depth[o]);
     }
 }
+
+// k_sky's blocks as a launch of their own: for frames so tall that k_colT's blocks are far larger than SKY_NT threads (its
+// launch would then start thousands of 1024-thread blocks for the sky units)
+__global__ __launch_bounds__(SKY_NT) void k_sky(const int *__restrict__ finfo, int H, int W, const float *dt_src, float *out_dt, float *out_depth,
+                                                int32_t *out_index, int nstrips) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_skyraw[];
+    sky_body(s_skyraw, finfo, H, W, dt_src, out_dt, out_depth, out_index, (int)blockIdx.x % nstrips, (int)blockIdx.x / nstrips);
+}

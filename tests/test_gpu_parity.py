@@ -922,7 +922,7 @@ def test_rows_marked_up_front_for_the_any_distance_kernels(gpu_op, oracle, pkg):
         a[~keep] = 0
         return a
 
-    for H, W in ((352, 1216), (417, 1000), (200, 640)):
+    for H, W in ((352, 1216), (417, 1000), (200, 640), (700, 300)):  # (700 rows: k_sky as a launch of its own)
         frames = []
         for top in (9, 17, 40, 87, 88, 100, H - 12):
             frames.append(rings(H, W, top, 4, 0.25))
