@@ -1,4 +1,5 @@
-"""Randomised soak: HIP path (auto + general, and l2) against the oracle on many random frames.
+"""Randomised soak: HIP path (auto + general, and l2; the fused outlier filter on both paths, with negative values; the depth
+epilogue; every subset of the outputs) against the oracle on many random frames.
 Usage on the GPU box: python scripts/soak.py [n_cases] [seed]"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -67,12 +68,30 @@ for t in range(n):
                 os.makedirs("gpurun_out", exist_ok=True)
                 np.savez_compressed("gpurun_out/mismatch_l2_%d_%s.npz" % (t, path), x=x, got=r["index"].cpu().numpy(), want=idx2)
     if t % 7 == 0 and H >= 4 and W >= 4:  # outlier_removal() in front of the predicates == the two passes composed
-        xf = np.stack([O.outlier_removal(f) for f in x]).astype(np.float32)
+        xo = x.copy()
+        if t % 14 == 0:  # negative values: the exhaustive second launch (every pixel a candidate)
+            xo[rng.random(x.shape) < 0.002] = -rng.uniform(1, 40)
+        xf = np.stack([O.outlier_removal(f) for f in xo]).astype(np.float32)
         depth_f, dt_f, lbl_f, st_f = O.fill_batch(xf)
-        r = op.run(xd, outlier_removal=True); torch.cuda.synchronize()
-        if not (np.array_equal(r["index"].cpu().numpy(), lbl_f) and np.array_equal(r["dt"].cpu().numpy(), dt_f)
-                and np.array_equal(r["depth"].cpu().numpy()[st_f == 0], depth_f[st_f == 0], equal_nan=True)):
-            bad += 1; print("FUSED OUTLIER MISMATCH case", t, (B, H, W), p)
+        for path in ("auto", "general"):
+            r = op.run(torch.from_numpy(xo).cuda(), outlier_removal=True, path=path); torch.cuda.synchronize()
+            if not (np.array_equal(r["index"].cpu().numpy(), lbl_f) and np.array_equal(r["dt"].cpu().numpy(), dt_f)
+                    and np.array_equal(r["depth"].cpu().numpy()[st_f == 0], depth_f[st_f == 0], equal_nan=True)):
+                bad += 1; print("FUSED OUTLIER MISMATCH case", t, path, (B, H, W), p)
+    if t % 5 == 0:  # the drivers' post-fill steps folded into the depth stores (demo.py:292-293, eval_NYU.py:205): rows from r0, floored
+        r0e = int(rng.integers(0, H)); fl = float(rng.choice([0.9, 5.0]))
+        r = op.run(xd, want=("depth",), depth_rows_from=r0e, depth_floor=fl); torch.cuda.synchronize()
+        ok = st == 0
+        if not np.array_equal(r["depth"].cpu().numpy()[ok], O.depth_floor(depth[:, r0e:], fl)[ok], equal_nan=True):
+            bad += 1; print("EPILOGUE MISMATCH case", t, (B, H, W), p, r0e, fl)
+    if t % 3 == 0:  # every subset of the outputs (k_sky takes its base rows' distances from a scratch map when none is wanted)
+        for want in (("depth",), ("index",), ("dt",), ("depth", "index")):
+            r = op.run(xd, want=want); torch.cuda.synchronize()
+            for k, ref in (("depth", depth), ("dt", dt), ("index", lbl)):
+                if k in want:
+                    g = r[k].cpu().numpy()
+                    if not (np.array_equal(g[st == 0], ref[st == 0], equal_nan=True) if k == "depth" else np.array_equal(g, ref)):
+                        bad += 1; print("OPTIONAL OUTPUT MISMATCH case", t, want, k, (B, H, W), p)
     npx += B * H * W
     if t % 25 == 0: print("case", t, "bad", bad, "%.0fs" % (time.time() - t0), flush=True)
 print("soak done:", n, "cases,", npx, "pixels, mismatches:", bad)
