@@ -335,7 +335,13 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     //          vd above a window kernel's reach (PM16 / PM32) cannot be decided by it: it is handed to the any-distance kernels
     //          up front (flag 1), and the window kernel takes the rest of the frame instead of nothing.
     // "Row has no source" as bits in LDS (H <= 8191 -> 256 words); the rows past H count as empty.
-    {
+    // (a frame in which every row holds a source -- the common dense one -- has vd = 0 everywhere: nothing to search)
+    bool someempty = false;
+    for (int w = tid; w <= (H - 1) >> 5; w += 256) someempty |= (s_empty[w] & (w == (H - 1) >> 5 ? (2u << ((H - 1) & 31)) - 1u : 0xFFFFFFFFu)) != 0u;
+    someempty = __syncthreads_or(someempty);
+    if (!someempty) {
+        s_far[0][tid] = s_far[1][tid] = 0u;
+    } else {
         int dlb = 0;
         const int lastw = (H - 1) >> 5, r0 = s_r0;
         for (int base = 0; base < Hp; base += 256) {

@@ -75,12 +75,14 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
         }
     }
     __syncthreads();
+    // a wave whose 64 columns lie beyond the image (the last tile column of a 640-wide frame: half of it) has no pixel to decide
+    const bool wave_idle = c0 + 64 * wave >= W;
     // ---- 1 + 2. this wave's candidates: box = rows r0 - 2 .. r0 + 33, columns wc0 - 2 .. wc0 + 65 (the edge waves' ring columns).
     // The list holds indices into the frame's list, in raster order (the frame's list is, and every compaction keeps it).
     const int wc0 = c0 + 64 * wave;
     u16 *wc = reinterpret_cast<u16 *>(s_raw + P_OFF_BYTE) + wave * PTS_MAX;
     int nw = 0;  // wave-uniform
-    {
+    if (!wave_idle) {
         // doubled coordinates: the centre sits on a half pixel
         const int cy2 = 2 * r0 + Q_TH - 1, cx2 = 2 * wc0 + 63;
         constexpr int RHO2 = (Q_TH + 3) + (64 + 3);  // centre to corner, doubled
@@ -228,12 +230,16 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                 }
             }
         };
-        if (nw <= 64)
+        if (wave_idle) {
+            for (int row = 0; row < P_NR; ++row) s_src[row][2 + 64 * wave + lane] = 0;  // no plane bits: outside the image
+        } else if (nw <= 64)
             run(std::true_type{});
         else
             run(std::false_type{});
         // the ring's columns: c0 - 2, c0 - 1 (wave 0) and c0 + 256, c0 + 257 (the last wave); lane = box row
-        if (wave == 0 || wave == Q_NT / 64 - 1) {
+        if (wave_idle && wave == Q_NT / 64 - 1) {
+            if (lane < P_NR) s_src[lane][Q_TW + 2] = s_src[lane][Q_TW + 3] = 0;
+        } else if (wave == 0 || wave == Q_NT / 64 - 1) {
             const int jb = wave == 0 ? c0 - 2 : c0 + Q_TW;
             const int row = lane, i = r0 - 2 + row;
 #pragma unroll
