@@ -180,8 +180,10 @@ def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, w
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    # defaults: the first few hundred passes after an idle spell run at ramping clocks (96 us per pass with 10 warm-up passes, 90.7
+    # with 300 and ever after); both loops together still take a twentieth of a second
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default: the workload's)")
     ap.add_argument("--workload", default="kitti_b32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -317,7 +319,7 @@ def main():
             for name in EXTRA_WORKLOADS:
                 c = synth.CONFIGS[name]
                 xw = torch.from_numpy(synth.make(name)).to(dev)
-                r, rf = measure(op, torch, xw, 30, 10, args.path, barrier, reduce_max, workload=name, traffic=traffic)
+                r, rf = measure(op, torch, xw, 30, 50, args.path, barrier, reduce_max, workload=name, traffic=traffic)
                 wl[name] = {"value": round(c["B"] * 30 / r["elapsed"], 1), "unit": "frames/s", "frames": c["B"],
                             "shape": [c["H"], c["W"]], "ms_per_step": r["ms_per_step"], "roofline": rf,
                             "frames_on_general_path": r["frames_on_general_path"]}
@@ -329,7 +331,7 @@ def main():
             for name in (args.workload,) + tuple(EXTRA_WORKLOADS):
                 c = synth.CONFIGS[name]
                 xw = x if name == args.workload else torch.from_numpy(synth.make(name)).to(dev)
-                r, rf = measure(op2, torch, xw, 30, 10, "auto", barrier, reduce_max, workload=name + "_l2", traffic=traffic)
+                r, rf = measure(op2, torch, xw, 30, 50, "auto", barrier, reduce_max, workload=name + "_l2", traffic=traffic)
                 l2[name] = {"value": round(xw.shape[0] * 30 / r["elapsed"], 1), "unit": "frames/s", "frames": int(xw.shape[0]),
                             "ms_per_step": r["ms_per_step"], "roofline": rf}
                 del xw

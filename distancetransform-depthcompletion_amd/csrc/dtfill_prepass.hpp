@@ -257,13 +257,15 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     u32 *bs_ = rowbase_s + (size_t)b * H, *bv_ = rowbase_v + (size_t)b * H;
     __shared__ u32 s_empty[256];   // bit i: row i holds no source (the rows past H count as empty)
     __shared__ u32 s_far[2][256];  // bit i: row i >= r0 and vd(i) > PM16 / > PM32
-    __shared__ int s_nfar[2], s_r0, s_route, s_bandmax;
+    __shared__ int s_nfar[2], s_r0, s_route, s_bandmax, s_nrow;
+    __shared__ u16 s_ptrow[L2_PTS_MAX];  // rows that hold a source (for the source list of a k_pts frame)
     const int Hp = (H + 63) & ~63;
     if (tid == 0) {
         s_mis = 0;
         s_dlb = 0;
         s_r0 = H;
         s_bandmax = 0;
+        s_nrow = 0;
     }
     if (tid < 2) s_nfar[tid] = 0;
     for (int w = tid + (Hp >> 5); w < 256; w += 256) s_empty[w] = 0xFFFFFFFFu;
@@ -292,6 +294,12 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
 #pragma unroll
             for (int o = 1; o < 32; o <<= 1) c += (u32)__shfl_xor((int)c, o);
             if ((lane & 31) == 0 && c) atomicMax(&s_bandmax, (int)c);
+            // ... and the rows that hold a source, listed (in any order; at most L2_PTS_MAX matter: a frame with more of them
+            // is no k_pts frame)
+            int at = 0;
+            if (lane == 0 && has) at = atomicAdd(&s_nrow, __popcll(has));
+            at = __builtin_amdgcn_readfirstlane(at) + (int)__builtin_amdgcn_mbcnt_hi((u32)(has >> 32), __builtin_amdgcn_mbcnt_lo((u32)has, 0u));
+            if (cs != 0u && at < L2_PTS_MAX) s_ptrow[at] = (u16)i;
         }
         u32 is = cs, iv = cv;
 #pragma unroll
@@ -416,35 +424,31 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     if (!l2 && r == ROUTE_POINTS) {
         // the frame's sources in raster order (index = label - 1), for k_pts
         PtsSrc *list = ptslist + (size_t)b * L2_PTS_MAX;
-        // a thread per row that holds a source (few do); the row's words four at a time (independent loads)
-        for (int i = tid; i < H; i += 256) {
-            if (cs_[i] == 0) continue;
-            const u64 *row = srcbits + ((size_t)b * H + i) * Wd;
-            u32 k = bs_[i];  // (this block wrote bs_ above, before a barrier)
-            for (int w0 = 0; w0 < Wd; w0 += 4) {
-                u64 sb[4];
+        const float *xf = x + (size_t)b * H * W;
+        // an item = one 64-pixel word of a row that holds a source (the rows were listed above); a word's sources go to their
+        // raster ranks; two items per step (independent loads)
+        const int nitems = min(s_nrow, L2_PTS_MAX) * Wd;
+        for (int it0 = tid; it0 < nitems; it0 += 512) {
+            u64 sb[2];
+            int row[2], w[2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) sb[q] = w0 + q < Wd ? row[w0 + q] : 0ull;
+            for (int q = 0; q < 2; ++q) {
+                const int it = it0 + 256 * q;
+                row[q] = s_ptrow[min(it, nitems - 1) / Wd];
+                w[q] = min(it, nitems - 1) % Wd;
+                sb[q] = it < nitems ? srcbits[((size_t)b * H + row[q]) * Wd + w[q]] : 0ull;
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    u64 m = sb[q];
-                    while (m) {
-                        const int j = (w0 + q) * 64 + __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        list[k++].rc = (u32)i << 16 | (u32)j;
-                    }
+            for (int q = 0; q < 2; ++q) {
+                u64 m = sb[q];
+                if (!m) continue;
+                u32 k = bs_[row[q]] + wpre_s[((size_t)b * H + row[q]) * Wd + w[q]];  // (this block wrote bs_ above, before a barrier)
+                while (m) {
+                    const int j = w[q] * 64 + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    list[k++] = PtsSrc{(u32)row[q] << 16 | (u32)j, xf[(size_t)row[q] * W + j]};  // ... with its depth
                 }
             }
-        }
-    }
-    if (!l2 && r == ROUTE_POINTS) {
-        // ... and their depths, every source by a thread of its own (one round trip for all of them)
-        __syncthreads();
-        PtsSrc *list = ptslist + (size_t)b * L2_PTS_MAX;
-        const float *xf = x + (size_t)b * H * W;
-        for (int k = tid; k < (int)run_s; k += 256) {
-            const u32 rc = list[k].rc;
-            list[k].v = xf[(size_t)(rc >> 16) * W + (rc & 0xFFFFu)];
         }
     }
     const bool flags = !l2 && premark && r >= 0;  // this frame's rows carry flags

@@ -16,12 +16,13 @@
 //      no pixel's nearest (not even tied) and drop out: about one source per cell the box touches survives (5 - 8 of 200);
 //   3. per pixel (lane = column, rows in registers) three packed-key minima over the survivors (v_sad_u16 is the L1
 //      distance of two packed (row, column) pairs):
-//        K1 = min d << 9 | idx, K2 = min d << 9 | (511 - idx): the smallest and largest list index among the nearest
-//        sources -- equal iff the pixel has ONE nearest source (then that is its label: chains end on a nearest source);
+//        K1 = the smallest key d << 15 | list index << 6 | position in the wave's list, M2 = the second smallest (v_med3):
+//        their distances differ iff the pixel has ONE nearest source (then that is its label: chains end on a nearest source);
 //        K3 = min over the sources at or above the pixel's row of d << 13 | column: live(q) iff the leftmost nearest source
 //        at or above q's row exists and has 3 (col - q.col) <= 2 d (the forward cone, as in k_rows);
-//      d goes straight to the distance map; d mod 8, live, tie and "in the image" become k_fin's bit planes in LDS (a ballot
-//      per plane and row), the nearest source's list index goes to LDS for every box pixel;
+//      d goes straight to the distance map, and so do label and depth of a pixel with one nearest source; d mod 8, live, tie and
+//      "in the image" ride with the nearest source's list index in an LDS array over the box and are gathered into k_fin's
+//      bit planes by a thread per word;
 //   4. k_fin's second half on those planes: bit-sliced 5x5 parent rule for the tie pixels, hops through the step bytes,
 //      every pixel takes the list index of the pixel its chain ends on: label = index + 1, depth = depth_list[label - 1]
 //      (the source's own value when the masks agree).  A chain that leaves the tile while still on tie pixels is handed to
@@ -134,7 +135,7 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
         }
     }
     // ---- 3. per pixel: the minima over the wave's candidates.  Lane = column wc0 + lane, P_RC rows at a time in registers.
-    //   K1 = the smallest key d << 9 | index, M2 = the second smallest (v_med3 of the two and the newcomer): one nearest
+    //   K1 = the smallest key d << 15 | index << 6 | position, M2 = the second smallest (v_med3 of the two and the newcomer): one nearest
     //   source iff their distances differ; K3 over the candidates at or above the row: the list is in raster order, so those
     //   are a prefix of it -- all rows of a chunk share the candidates above its first row (no test), none has those below its
     //   last row (no K3 at all), only the few inside the chunk's rows are tested row by row.
@@ -176,21 +177,22 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                     nB += __popcll(__ballot(sr <= ib + P_RC - 1));
                 }
                 auto body = [&](int c, auto mode) {
-                    // the low 9 bits of the keys: FAST the position in the wave's list (same order as the list index), else the index
+                    // the low 15 bits of the keys: list index << 6 | position in the wave's list (FAST; both in the list's order)
                     u32 idx, rc;
                     if (FAST) {
-                        idx = (u32)c;
+                        idx = (u32)__builtin_amdgcn_readlane((int)myidx, c) << 6 | (u32)c;
                         rc = (u32)__builtin_amdgcn_readlane((int)myrc, c);
                     } else {
                         idx = (u32)__builtin_amdgcn_readfirstlane((int)wc[c]);
                         rc = (u32)__builtin_amdgcn_readfirstlane((int)s_rc[idx]);
+                        idx <<= 6;
                     }
                     const u32 sp = rc + (4u << 16 | 4u), colkey = rc & 0xFFFFu;
                     const int sr = (int)(rc >> 16);
 #pragma unroll
                     for (int u = 0; u < P_RC; ++u) {
                         const u32 d = __builtin_amdgcn_sad_u16(qb + ((u32)u << 16), sp, 0u);
-                        const u32 key = d << 9 | idx;
+                        const u32 key = d << 15 | idx;
                         M2[u] = med3u(K1[u], M2[u], key);  // K1 <= M2: the second smallest of the three
                         K1[u] = min(K1[u], key);
                         if (decltype(mode)::value == 0) {
@@ -207,9 +209,8 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                 for (int u = 0; u < P_RC; ++u) {
                     const int row = rb + u, i = ib + u;  // wave-uniform
                     const bool rin = i >= 0 && i < H;
-                    const u32 d = K1[u] >> 9, lo9 = K1[u] & 511u;
-                    const u32 i1 = FAST ? (u32)__shfl((int)myidx, (int)lo9) : lo9;
-                    const bool tie = ((M2[u] >> 9) == d) & (d != 0u);
+                    const u32 d = K1[u] >> 15, i1 = (K1[u] >> 6) & 511u, pos = K1[u] & 63u;
+                    const bool tie = ((M2[u] >> 15) == d) & (d != 0u);
                     const bool live = ((K3[u] >> 13) == d) & (3 * (int)(K3[u] & 8191u) <= (int)(2u * d) + 3 * j);
                     // the pixel's plane bits ride with its index: d mod 8 | live << 3 | tie << 4 | in-image << 5 (all zero outside)
                     const u32 code = (rin && jin) ? ((d & 7u) | (live ? 8u : 0u) | (tie ? 16u : 0u) | 32u) : 0u;
@@ -217,7 +218,7 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                     if (row >= 2 && row < Q_TH + 2) {  // (compile-time per unrolled row of a chunk)
                         // the tile's own pixels: the distance now; label and depth too unless a chain has to be followed (phase 4)
                         float val = 0.0f;
-                        if (dp_f) val = (FAST && !misaligned) ? __shfl(myval, (int)lo9) : 0.0f;
+                        if (dp_f) val = (FAST && !misaligned) ? __shfl(myval, (int)pos) : 0.0f;
                         if (rin && jin) {
                             const u32 ob = (u32)(__umul24((u32)i, (u32)W) + (u32)j) << 2;
                             if (dt_f) st_off_nt(dt_f, ob, (float)d);
