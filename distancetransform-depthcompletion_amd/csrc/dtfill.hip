@@ -237,8 +237,11 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         pa.xptr = c.xptr;
         pa.unres = c.planes + PL_UNRES * c.plane_bytes;
         pa.Wp = Wd * 8;
-        pa.tiles_x = (W + Q_TW - 1) / Q_TW;
-        pa.ntiles = rowflags ? pa.tiles_x * ((H + Q_TH - 1) / Q_TH) : 0;
+        // 32 x 256 tiles or 64 x 128: whichever wastes fewer waves on this shape (640 columns are 2.5 tiles of 256 but 5 of 128)
+        const int nwide = ((W + 255) / 256) * ((H + 31) / 32), ntall = ((W + 127) / 128) * ((H + 63) / 64);
+        pa.tall = ntall < nwide;
+        pa.tiles_x = pa.tall ? (W + 127) / 128 : (W + 255) / 256;
+        pa.ntiles = rowflags ? (pa.tall ? ntall : nwide) : 0;
         const dim3 fg(max(max(t16.ntiles, t32.ntiles), pa.ntiles), B);
         if (stream)
             k_fused<true><<<fg, F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd, t16, t32, out_depth, out_dt,

@@ -557,14 +557,16 @@ __device__ __forceinline__ void fused_body(bool premarked,
 // the block's LDS: one buffer, carved here for the window kernel and in dtfill_pts.hpp for a k_pts tile
 constexpr size_t F_OFF_RW = (sizeof(u32) * F_RING + 15) & ~(size_t)15, F_OFF_TAB = F_OFF_RW + sizeof(uint2) * F_WHM * 8, F_OFF_ANY = F_OFF_TAB + sizeof(short) * 64,
                  F_LDS_OWN = F_OFF_ANY + sizeof(u32) * 2 * (F_NT / 64);
-constexpr size_t F_LDS = F_LDS_OWN < 38736 ? 38736 : F_LDS_OWN;  // (>= PTS_LDS: checked where that is defined)
+constexpr size_t F_LDS = F_LDS_OWN < 39904 ? 39904 : F_LDS_OWN;  // (>= a k_pts block's: checked where that is defined)
 
 struct PtsArgs {  // what a k_pts tile needs beyond the window kernel's own arguments
     const PtsSrc *ptslist;
     u32 *xlist, *xptr;
     u8 *unres;
     int Wp, tiles_x, ntiles;
+    int tall;  // tiles of 64 x 128 instead of 32 x 256
 };
+template <int TH, int TW>
 __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, const float *__restrict__ x, const PtsSrc *__restrict__ ptslist, int H,
                                          int W, int Wp, int tiles_x, const float *__restrict__ vlist, float *__restrict__ out_depth,
                                          float *__restrict__ out_dt, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
@@ -587,8 +589,12 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const int rt = route[blockIdx.y];        // block-uniform
     if (rt == ROUTE_POINTS) {
         // a frame with a handful of sources: its 32 x 256 tiles ride in this launch (dtfill_pts.hpp)
-        if ((int)blockIdx.x < pa.ntiles)
-            pts_body(s_raw, x, pa.ptslist, H, W, pa.Wp, pa.tiles_x, vlist, out_depth, out_dt, out_index, frame_status, finfo, pa.xlist, pa.xptr, pa.unres);
+        if ((int)blockIdx.x < pa.ntiles) {
+            if (pa.tall)
+                pts_body<64, 128>(s_raw, x, pa.ptslist, H, W, pa.Wp, pa.tiles_x, vlist, out_depth, out_dt, out_index, frame_status, finfo, pa.xlist, pa.xptr, pa.unres);
+            else
+                pts_body<32, 256>(s_raw, x, pa.ptslist, H, W, pa.Wp, pa.tiles_x, vlist, out_depth, out_dt, out_index, frame_status, finfo, pa.xlist, pa.xptr, pa.unres);
+        }
         return;
     }
     const int r = rt > 0 ? (rt & 0xFF) : 0;

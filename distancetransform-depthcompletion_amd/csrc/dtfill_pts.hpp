@@ -29,10 +29,24 @@
 //      k_tiesx exactly as k_fin does.
 // ------------------------------------------------------------------------------------------------
 constexpr int PTS_MAX = L2_PTS_MAX;       // 512: the list index has 9 bits in the keys
-constexpr int P_NR = Q_TH + 4;            // rows of the box
-constexpr int P_SP = Q_TW + 4;            // pitch of the index array: columns c0 - 2 .. c0 + 257
+constexpr int P_WB = 36;                  // rows of a wave's box: its 32 rows + 2 either side
 constexpr int P_RC = 12;                  // rows per register chunk
-static_assert(P_NR % P_RC == 0, "whole chunks");
+static_assert(P_WB % P_RC == 0, "whole chunks");
+
+// A block's tile is TH x TW pixels = (TH / 32) x (TW / 64) waves of 32 rows x 64 columns: 32 x 256 (k_fin's tile) or 64 x 128 --
+// the host picks the one that wastes fewer waves on the frame's shape (a 640-wide frame is 2.5 tiles of 256 but 5 of 128).
+template <int TH, int TW>
+struct PtsGeom {
+    static_assert(TH % 32 == 0 && TW % 64 == 0 && (TH / 32) * (TW / 64) == Q_NT / 64 && TH * (TW / 32) == Q_NT, "four waves, a thread per word");
+    static constexpr int WW = TW / 32, RS = WW + 3, NR = TH + 4, SP = TW + 4, NWC = TW / 64;
+    // LDS of one block, carved from the window kernel's buffer (the tiles of such frames ride in k_fused's launch)
+    static constexpr size_t OFF_BYTE = (sizeof(u32) * 6 * NR * RS + 15) & ~(size_t)15, OFF_SRC = OFF_BYTE + TH * TW,
+                            OFF_RC = (OFF_SRC + sizeof(u16) * NR * SP + 3) & ~(size_t)3, OFF_LIST = OFF_RC + sizeof(u32) * PTS_MAX,
+                            OFF_CNT = OFF_LIST + Q_NT, LDS = OFF_CNT + sizeof(u32) * (Q_NT / 64);
+    static_assert(SP % 2 == 0, "rows of the index array are 4-byte aligned");
+    static_assert(LDS <= F_LDS, "k_fused's buffer holds a k_pts block");
+    static_assert((size_t)TH * TW >= (Q_NT / 64) * PTS_MAX * sizeof(u16), "the candidate lists live in s_byte until the planes are done");
+};
 
 __device__ __forceinline__ u32 med3u(u32 a, u32 b, u32 c) {
     u32 r;
@@ -40,27 +54,25 @@ __device__ __forceinline__ u32 med3u(u32 a, u32 b, u32 c) {
     return r;
 }
 
-// LDS of one block, carved from the window kernel's buffer (the tiles of such frames ride in k_fused's launch)
-constexpr size_t P_OFF_BYTE = sizeof(u32) * 6 * P_NR * Q_RS, P_OFF_SRC = P_OFF_BYTE + Q_TH * Q_TW, P_OFF_RC = P_OFF_SRC + sizeof(u16) * P_NR * P_SP,
-                 P_OFF_LIST = P_OFF_RC + sizeof(u32) * PTS_MAX, P_OFF_CNT = P_OFF_LIST + Q_NT, PTS_LDS = P_OFF_CNT + sizeof(u32) * (Q_NT / 64);
-static_assert(P_OFF_BYTE % 16 == 0 && P_OFF_SRC % 4 == 0 && P_OFF_RC % 4 == 0 && P_OFF_CNT % 4 == 0, "alignment of the carve");
-static_assert(PTS_LDS <= F_LDS, "k_fused's buffer holds a k_pts block");
-
+template <int TH, int TW>
 __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, const float *__restrict__ x, const PtsSrc *__restrict__ ptslist, int H,
                                          int W, int Wp, int tiles_x, const float *__restrict__ vlist, float *__restrict__ out_depth,
                                          float *__restrict__ out_dt, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
                                          int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres) {
-    u32(*s_pl)[P_NR][Q_RS] = reinterpret_cast<u32(*)[P_NR][Q_RS]>(s_raw);  // d bit 0, 1, 2, live, tie, in-image; rows r0-2 .. r0+33; word 0 / 9: the ring's
-    u8(*s_byte)[Q_TW] = reinterpret_cast<u8(*)[Q_TW]>(s_raw + P_OFF_BYTE);  // per tile pixel: step to its parent; before that: the waves' candidate lists
-    u16(*s_src)[P_SP] = reinterpret_cast<u16(*)[P_SP]>(s_raw + P_OFF_SRC);  // per box pixel: list index of its nearest source | plane bits << 9
-    u32 *s_rc = reinterpret_cast<u32 *>(s_raw + P_OFF_RC);                 // the frame's sources: row << 16 | column; later their depths
-    u8 *s_list = s_raw + P_OFF_LIST;                                        // the listed words (phase 4)
-    u32 *s_cnt = reinterpret_cast<u32 *>(s_raw + P_OFF_CNT);
-    static_assert(Q_TH * Q_TW >= (Q_NT / 64) * PTS_MAX * sizeof(u16), "the candidate lists live in s_byte until the planes are done");
+    using G = PtsGeom<TH, TW>;
+    constexpr int WW = G::WW, RS = G::RS, NR = G::NR, SP = G::SP, NWC = G::NWC;
+    u32(*s_pl)[NR][RS] = reinterpret_cast<u32(*)[NR][RS]>(s_raw);      // d bit 0, 1, 2, live, tie, in-image; rows r0-2 .. r0+TH+1; word 0 / WW+1: the ring's
+    u8(*s_byte)[TW] = reinterpret_cast<u8(*)[TW]>(s_raw + G::OFF_BYTE);  // per tile pixel: step to its parent; before that: the waves' candidate lists
+    u16(*s_src)[SP] = reinterpret_cast<u16(*)[SP]>(s_raw + G::OFF_SRC);  // per box pixel: list index of its nearest source | plane bits << 9
+    u32 *s_rc = reinterpret_cast<u32 *>(s_raw + G::OFF_RC);              // the frame's sources: row << 16 | column; later their depths
+    u8 *s_list = s_raw + G::OFF_LIST;                                     // the listed words (phase 4)
+    u32 *s_cnt = reinterpret_cast<u32 *>(s_raw + G::OFF_CNT);
     const int b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int r0 = ty * Q_TH, c0 = tx * Q_TW;
+    const int r0 = ty * TH, c0 = tx * TW;
+    const int wr = wave / NWC, wcol = wave - wr * NWC;  // the wave's place in the tile
+    const int r0w = r0 + 32 * wr;                        // its first row
     const int nsrc = finfo[b * FI_STRIDE + FI_NSRC];
     const PtsSrc *sl = ptslist + (size_t)b * PTS_MAX;
     const u32 fo = (u32)b * (u32)(H * W);
@@ -77,16 +89,16 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
     }
     __syncthreads();
     // a wave whose 64 columns lie beyond the image (the last tile column of a 640-wide frame: half of it) has no pixel to decide
-    const bool wave_idle = c0 + 64 * wave >= W;
+    const bool wave_idle = c0 + 64 * wcol >= W || r0w >= H;
     // ---- 1 + 2. this wave's candidates: box = rows r0 - 2 .. r0 + 33, columns wc0 - 2 .. wc0 + 65 (the edge waves' ring columns).
     // The list holds indices into the frame's list, in raster order (the frame's list is, and every compaction keeps it).
-    const int wc0 = c0 + 64 * wave;
-    u16 *wc = reinterpret_cast<u16 *>(s_raw + P_OFF_BYTE) + wave * PTS_MAX;
+    const int wc0 = c0 + 64 * wcol;
+    u16 *wc = reinterpret_cast<u16 *>(s_raw + G::OFF_BYTE) + wave * PTS_MAX;
     int nw = 0;  // wave-uniform
     if (!wave_idle) {
         // doubled coordinates: the centre sits on a half pixel
-        const int cy2 = 2 * r0 + Q_TH - 1, cx2 = 2 * wc0 + 63;
-        constexpr int RHO2 = (Q_TH + 3) + (64 + 3);  // centre to corner, doubled
+        const int cy2 = 2 * r0w + 32 - 1, cx2 = 2 * wc0 + 63;
+        constexpr int RHO2 = (32 + 3) + (64 + 3);  // centre to corner, doubled
         u32 dmin = 0xFFFFFFFFu;
         for (int k = lane; k < nsrc; k += 64) {
             const u32 rc = s_rc[k];
@@ -113,8 +125,8 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
         // compacted in place: whatever a later chunk still finds in the front part of the list is a real source of the frame,
         // and being dominated by any real source is reason enough to go.
         const u32 off = 4u << 16 | 4u;
-        const u32 ca = (u32)(r0 - 2 + 4) << 16 | (u32)(wc0 - 2 + 4), cb = (u32)(r0 - 2 + 4) << 16 | (u32)(wc0 + 65 + 4),
-                  cc = (u32)(r0 + Q_TH + 1 + 4) << 16 | (u32)(wc0 - 2 + 4), cd = (u32)(r0 + Q_TH + 1 + 4) << 16 | (u32)(wc0 + 65 + 4);
+        const u32 ca = (u32)(r0w - 2 + 4) << 16 | (u32)(wc0 - 2 + 4), cb = (u32)(r0w - 2 + 4) << 16 | (u32)(wc0 + 65 + 4),
+                  cc = (u32)(r0w + 32 + 1 + 4) << 16 | (u32)(wc0 - 2 + 4), cd = (u32)(r0w + 32 + 1 + 4) << 16 | (u32)(wc0 + 65 + 4);
         for (int k0 = 0; k0 < n; k0 += 64) {
             const int k = k0 + lane;
             const u32 me = wc[min(k, n - 1)];
@@ -163,11 +175,11 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
             const u32 myidx = lane < nw ? (u32)wc[lane] : 0u;
             const u32 myrc = s_rc[myidx];
             const float myval = (FAST && dp_f && !misaligned && lane < nw) ? sl[myidx].v : 0.0f;
-            for (int rb = 0; rb < P_NR; rb += P_RC) {
+            for (int rb = 0; rb < P_WB; rb += P_RC) {
                 u32 K1[P_RC], M2[P_RC], K3[P_RC];
 #pragma unroll
                 for (int u = 0; u < P_RC; ++u) K1[u] = M2[u] = K3[u] = 0xFFFFFFFFu;
-                const int ib = r0 - 2 + rb;  // image row of the chunk's first row (may be negative: such rows are masked below)
+                const int ib = r0w - 2 + rb;  // image row of the chunk's first row (may be negative: such rows are masked below)
                 const u32 qb = (u32)(ib + 4) << 16 | (u32)(j + 4);
                 // nA candidates lie at or above the chunk's first row, nB at or above its last
                 int nA = 0, nB = 0;
@@ -214,8 +226,8 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                     const bool live = ((K3[u] >> 13) == d) & (3 * (int)(K3[u] & 8191u) <= (int)(2u * d) + 3 * j);
                     // the pixel's plane bits ride with its index: d mod 8 | live << 3 | tie << 4 | in-image << 5 (all zero outside)
                     const u32 code = (rin && jin) ? ((d & 7u) | (live ? 8u : 0u) | (tie ? 16u : 0u) | 32u) : 0u;
-                    s_src[row][2 + 64 * wave + lane] = (u16)(i1 | code << 9);
-                    if (row >= 2 && row < Q_TH + 2) {  // (compile-time per unrolled row of a chunk)
+                    s_src[32 * wr + row][2 + 64 * wcol + lane] = (u16)(i1 | code << 9);
+                    if (row >= 2 && row < 34) {  // the wave's own 32 rows
                         // the tile's own pixels: the distance now; label and depth too unless a chain has to be followed (phase 4)
                         float val = 0.0f;
                         if (dp_f) val = (FAST && !misaligned) ? __shfl(myval, (int)pos) : 0.0f;
@@ -232,17 +244,22 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
             }
         };
         if (wave_idle) {
-            for (int row = 0; row < P_NR; ++row) s_src[row][2 + 64 * wave + lane] = 0;  // no plane bits: outside the image
+            // no plane bits: outside the image.  (Its first four rows are the last four of the wave above, which writes them.)
+            for (int row = wr ? 4 : 0; row < P_WB; ++row) s_src[32 * wr + row][2 + 64 * wcol + lane] = 0;
         } else if (nw <= 64)
             run(std::true_type{});
         else
             run(std::false_type{});
-        // the ring's columns: c0 - 2, c0 - 1 (wave 0) and c0 + 256, c0 + 257 (the last wave); lane = box row
-        if (wave_idle && wave == Q_NT / 64 - 1) {
-            if (lane < P_NR) s_src[lane][Q_TW + 2] = s_src[lane][Q_TW + 3] = 0;
-        } else if (wave == 0 || wave == Q_NT / 64 - 1) {
-            const int jb = wave == 0 ? c0 - 2 : c0 + Q_TW;
-            const int row = lane, i = r0 - 2 + row;
+        // the ring's columns: c0 - 2, c0 - 1 (the waves of the first wave column) and c0 + TW, c0 + TW + 1 (of the last); lane = box row
+        if (wave_idle && wcol == NWC - 1) {
+            if (lane >= (wr ? 4 : 0) && lane < P_WB) s_src[32 * wr + lane][TW + 2] = s_src[32 * wr + lane][TW + 3] = 0;
+        } else if (wave_idle) {
+            if (wcol == 0 && lane >= (wr ? 4 : 0) && lane < P_WB) s_src[32 * wr + lane][0] = s_src[32 * wr + lane][1] = 0;
+        } else {
+          for (int side = 0; side < 2; ++side) {  // the tile's left ring columns (first wave column), its right ones (last)
+            if (side == 0 ? wcol != 0 : wcol != NWC - 1) continue;
+            const int jb = side == 0 ? c0 - 2 : c0 + TW;
+            const int row = lane, i = r0w - 2 + row;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int jj = jb + e;
@@ -256,13 +273,14 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                     k1 = min(k1, key);
                     if ((int)(rc >> 16) <= i) k3 = min(k3, d << 13 | (rc & 0xFFFFu));
                 }
-                const bool in = row < P_NR && i >= 0 && i < H && jj >= 0 && jj < W;
+                const bool in = row < P_WB && i >= 0 && i < H && jj >= 0 && jj < W;
                 const u32 d = k1 >> 9, i1 = k1 & 511u;
                 const bool tie = ((m2 >> 9) == d) & (d != 0u);
                 const bool live = ((k3 >> 13) == d) & (3 * (int)(k3 & 8191u) <= (int)(2u * d) + 3 * jj);
                 const u32 code = in ? ((d & 7u) | (live ? 8u : 0u) | (tie ? 16u : 0u) | 32u) : 0u;
-                if (row < P_NR) s_src[row][wave == 0 ? e : Q_TW + 2 + e] = (u16)(i1 | code << 9);
+                if (row < P_WB) s_src[32 * wr + row][side == 0 ? e : TW + 2 + e] = (u16)(i1 | code << 9);
             }
+          }
         }
     }
     __syncthreads();  // every box pixel's index and plane bits are in s_src; the candidate lists (in s_byte) are dead
@@ -276,10 +294,10 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
         }
     }
     // ---- the bit planes k_fin's rule reads, 32 pixels per word: a thread per (box row, word) gathers bit p of 32 codes
-    for (int it = tid; it < P_NR * (Q_WW + 2); it += Q_NT) {
-        const int row = it / (Q_WW + 2), w = it - row * (Q_WW + 2);  // word 0 / Q_WW + 1: the ring's (two pixels each)
+    for (int it = tid; it < NR * (WW + 2); it += Q_NT) {
+        const int row = it / (WW + 2), w = it - row * (WW + 2);  // word 0 / WW + 1: the ring's (two pixels each)
         u32 pl[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-        if (w >= 1 && w <= Q_WW) {
+        if (w >= 1 && w <= WW) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const u32 *q4 = reinterpret_cast<const u32 *>(&s_src[row][2 + 32 * (w - 1) + 8 * g]);
@@ -291,7 +309,7 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                 }
             }
         } else {
-            const int cb = w == 0 ? 0 : Q_TW + 2, sh = w == 0 ? 30 : 0;
+            const int cb = w == 0 ? 0 : TW + 2, sh = w == 0 ? 30 : 0;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const u32 v = s_src[row][cb + e];
@@ -306,7 +324,7 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
     // ---- 4. the tie pixels: the tile's 32-pixel words that hold one are listed, one thread per listed word (the words
     // without one -- most, in a frame with a handful of sources -- cost nothing, and whole waves drop out): k_fin's bit-sliced
     // parent rule, step bytes, hops
-    int trow = tid / Q_WW, tw = tid % Q_WW;
+    int trow = tid / WW, tw = tid % WW;
     int total = 0;  // listed words (block-uniform)
     bool has = false;
     {
@@ -326,8 +344,8 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
         __syncthreads();  // (also: every thread has read the per-wave counts, s_cnt is free for the list append below)
         has = tid < total;
         const int mine = has ? (int)s_list[tid] : 0;
-        trow = mine / Q_WW;
-        tw = mine % Q_WW;
+        trow = mine / WW;
+        tw = mine % WW;
     }
     const bool any_tie = total != 0;
     const int gi = r0 + trow, gw = (c0 >> 5) + tw;
@@ -396,7 +414,7 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
             int er = trow, ec = pc;
             bool open = true;
             for (int hop = 0; hop < Q_HOPS; ++hop) {
-                if (er < 0 || er >= Q_TH || ec < 0 || ec >= Q_TW) break;  // a tie pixel of another tile: no step here
+                if (er < 0 || er >= TH || ec < 0 || ec >= TW) break;  // a tie pixel of another tile: no step here
                 const u32 bb = s_byte[er][ec] & 63u;
                 er += (int)(bb >> 3) - 2;
                 ec += (int)(bb & 7u) - 2;
@@ -411,7 +429,7 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                 const int ei = min(max(r0 + er, 0), H - 1), ej = min(max(c0 + ec, 0), W - 1);
                 xptr[fo + pix] = (u32)(ei * W + ej);
             } else {
-                const u32 idx = s_src[min(max(er, -2), Q_TH + 1) + 2][min(max(ec, -2), Q_TW + 1) + 2] & 511u;
+                const u32 idx = s_src[min(max(er, -2), TH + 1) + 2][min(max(ec, -2), TW + 1) + 2] & 511u;
                 if (ix_f) ix_f[pix] = (int32_t)idx + 1;
                 bad |= misaligned && (int)idx >= nval;
                 if (dp_f) dp_f[pix] = __uint_as_float(s_rc[idx]);

@@ -540,6 +540,8 @@ def test_l1_frames_with_a_handful_of_sources(gpu_op, oracle):
     assert_equal_to_oracle(oracle, gpu_op, x)
     for (H, W) in [(5, 7), (31, 33), (33, 31), (1, 100), (100, 1), (64, 257), (37, 1023)]:
         assert_equal_to_oracle(oracle, gpu_op, pts(H, W, min(3, H * W))[None])
+    for (H, W, n) in [(200, 300, 40), (480, 600, 150), (130, 129, 12), (65, 640, 30)]:  # shapes that take the 64 x 128 tiles, ragged either way
+        assert_equal_to_oracle(oracle, gpu_op, np.stack([pts(H, W, n), pts(H, W, 2 * n)]))
     x = np.stack([pts(128, 640, 60), pts(128, 640, 30)])
     x[0, 5, :40] = 0.5                    # values that are not sources: misaligned enumerations
     assert_equal_to_oracle(oracle, gpu_op, x)
