@@ -113,6 +113,28 @@ class DtFill:
         res["status"] = o["status"]
         return res
 
+    def upload(self, xh):
+        """Host frames [B,H,W] (any real dtype / strides) -> this operator's float32 device input buffer, asynchronously on the
+        current stream: a small thread pool copies the caller's pageable array into pinned staging memory a few frames at a
+        time (numpy releases the GIL inside the copy), every chunk's DMA starting as soon as its copy is done."""
+        B, H, W = xh.shape
+        self._ensure(B, H, W)
+        if getattr(self, "_pin_shape", None) != (B, H, W):
+            self._pin_in = torch.empty((B, H, W), dtype=torch.float32).pin_memory()
+            self._dev_in = torch.empty((B, H, W), dtype=torch.float32, device=self.device)
+            self._pin_status = torch.empty((B,), dtype=torch.int32).pin_memory()
+            self._pin_shape = (B, H, W)
+        nchunk = min(B, 8)
+        cuts = [B * c // nchunk for c in range(nchunk + 1)]
+        pin_in = self._pin_in.numpy()
+        pool = _copy_pool()
+        with torch.cuda.device(self.device):
+            stage = [pool.submit(np.copyto, pin_in[cuts[c]:cuts[c + 1]], xh[cuts[c]:cuts[c + 1]], "same_kind") for c in range(nchunk)]
+            for c in range(nchunk):
+                stage[c].result()  # (one pass: gathers strided input, casts if needed)
+                self._dev_in[cuts[c]:cuts[c + 1]].copy_(self._pin_in[cuts[c]:cuts[c + 1]], non_blocking=True)
+        return self._dev_in
+
     def pass_stats(self):
         """Which kernel family owned how many pixels in the last run() of this operator (dtfill_pass_stats): dict of ints."""
         B, H, W = self._shape
@@ -137,23 +159,10 @@ class DtFill:
         if xh.ndim != 3:
             raise ValueError("x must be [B,H,W]")
         B, H, W = xh.shape
-        self._ensure(B, H, W)
-        if getattr(self, "_pin_shape", None) != (B, H, W):
-            self._pin_in = torch.empty((B, H, W), dtype=torch.float32).pin_memory()
-            self._dev_in = torch.empty((B, H, W), dtype=torch.float32, device=self.device)
-            self._pin_status = torch.empty((B,), dtype=torch.int32).pin_memory()
-            self._pin_shape = (B, H, W)
-        nchunk = min(B, 8)
-        cuts = [B * c // nchunk for c in range(nchunk + 1)]
-        pin_in = self._pin_in.numpy()
-        pool = _copy_pool()
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device)
-            stage = [pool.submit(np.copyto, pin_in[cuts[c]:cuts[c + 1]], xh[cuts[c]:cuts[c + 1]], "same_kind") for c in range(nchunk)]
-            for c in range(nchunk):
-                stage[c].result()  # (one pass: gathers strided input, casts if needed)
-                self._dev_in[cuts[c]:cuts[c + 1]].copy_(self._pin_in[cuts[c]:cuts[c + 1]], non_blocking=True)
-            res = self.run(self._dev_in, src_thr, val_thr, want, depth_rows_from=depth_rows_from, depth_floor=depth_floor,
+            dev_in = self.upload(xh)
+            res = self.run(dev_in, src_thr, val_thr, want, depth_rows_from=depth_rows_from, depth_floor=depth_floor,
                            outlier_removal=outlier_removal)
             self._pin_status.copy_(res["status"], non_blocking=True)
             out = {}

@@ -277,7 +277,7 @@ def fill_sharded(x, src_thr=0.1, val_thr=0.1, metric="l1_cv", want=("depth", "dt
                 with torch.cuda.device(dev):
                     op = _device.default_op(metric)
                     if hi > lo:
-                        xd = torch.from_numpy(np.ascontiguousarray(x[lo:hi], dtype=np.float32)).to(dev, non_blocking=False)
+                        xd = op.upload(np.asarray(x)[lo:hi])  # pinned staging by a few threads, the DMA chunk by chunk behind them
                         res = op.run(xd, src_thr, val_thr, want)
                         t1 = time.perf_counter()
                         for k in slab.names:  # device -> this rank's slice of the slab, asynchronously, all outputs in flight
