@@ -286,6 +286,11 @@ def main():
                    "h2d_compute_ms": round(reduce_max(tm["compute_ms"]), 2),
                    "d2h_into_slab_ms": round(reduce_max(tm["gather_ms"]), 2),
                    "frames_per_s_end_to_end": round(xs.shape[0] / total, 1)}
+        # ... and with the one output DT_complete_batch returns (tools.py:13-35), for comparison with `end_to_end`
+        pkg.fill_sharded(xs, metric=args.metric, dst=0, want=("depth",))
+        t0 = time.perf_counter()
+        pkg.fill_sharded(xs, metric=args.metric, dst=0, want=("depth",))
+        sharded["depth_only_frames_per_s"] = round(xs.shape[0] / reduce_max(time.perf_counter() - t0), 1)
 
     if rank == 0:
         frames = world * B * args.steps
