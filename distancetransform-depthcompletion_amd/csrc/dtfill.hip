@@ -229,26 +229,13 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         // streaming stores only where every run of tile pixels a wave stores is whole 128-byte lines
         auto line = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 127) == 0; };
         const bool stream = (W & 31) == 0 && (t16.TW & 31) == 0 && (t32.TW & 31) == 0 && line(out_depth) && line(out_dt) && line(out_index);
-        // the frames with a handful of sources (k_frame: ROUTE_POINTS; only with the row flags) ride in the same launch: their
-        // 32 x 256 tiles, from the source list to the outputs (dtfill_pts.hpp); k_tiesx finishes the chains that leave a tile
-        PtsArgs pa;
-        pa.ptslist = c.ptslist;
-        pa.xlist = c.xlist;
-        pa.xptr = c.xptr;
-        pa.unres = c.planes + PL_UNRES * c.plane_bytes;
-        pa.Wp = Wd * 8;
-        // 32 x 256 tiles or 64 x 128: whichever wastes fewer waves on this shape (640 columns are 2.5 tiles of 256 but 5 of 128)
-        const int nwide = ((W + 255) / 256) * ((H + 31) / 32), ntall = ((W + 127) / 128) * ((H + 63) / 64);
-        pa.tall = ntall < nwide;
-        pa.tiles_x = pa.tall ? (W + 127) / 128 : (W + 255) / 256;
-        pa.ntiles = rowflags ? (pa.tall ? ntall : nwide) : 0;
-        const dim3 fg(max(max(t16.ntiles, t32.ntiles), pa.ntiles), B);
+        const dim3 fg(max(t16.ntiles, t32.ntiles), B);
         if (stream)
             k_fused<true><<<fg, F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd, t16, t32, out_depth, out_dt,
-                                               out_index, c.route, c.fflag2, status, ep, pa);
+                                               out_index, c.route, c.fflag2, status, ep);
         else
             k_fused<false><<<fg, F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd, t16, t32, out_depth, out_dt,
-                                                out_index, c.route, c.fflag2, status, ep, pa);
+                                                out_index, c.route, c.fflag2, status, ep);
     }
     mark();
     if (!fused_only) {
@@ -299,15 +286,27 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
             LAUNCH_ROWS(8, 1024);
 #undef LAUNCH_ROWS
         mark();
-        if (fin) {
-            const int ttx = (W + Q_TW - 1) / Q_TW, tty = (H + Q_TH - 1) / Q_TH;
+        // the frames with a handful of sources (k_frame: ROUTE_POINTS, fflag 3; only with the row flags) ride in k_fin's launch:
+        // their tiles, from the source list to the outputs (dtfill_pts.hpp); k_tiesx finishes the chains that leave a tile
+        PtsArgs pa;
+        pa.ptslist = c.ptslist;
+        pa.out_dt = out_dt;
+        // 32 x 256 tiles or 64 x 128: whichever wastes fewer waves on this shape (640 columns are 2.5 tiles of 256 but 5 of 128)
+        const int nwide = ((W + 255) / 256) * ((H + 31) / 32), ntall = ((W + 127) / 128) * ((H + 63) / 64);
+        pa.tall = ntall < nwide;
+        pa.tiles_x = pa.tall ? (W + 127) / 128 : (W + 255) / 256;
+        pa.ntiles = rowflags ? (pa.tall ? ntall : nwide) : 0;
+        const int ttx = (W + Q_TW - 1) / Q_TW, tty = (H + Q_TH - 1) / Q_TH;
+        pa.fin_ntiles = fin ? ttx * tty : 0;
+        if (fin || pa.ntiles) {
             const int vec = (W & 3) == 0 && aligned(out_depth, 16) && aligned(out_index, 16);
-            k_fin<<<dim3(ttx * tty, B), Q_NT, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, Wd, ttx, c.spix, x, c.rec,
+            k_fin<<<dim3(max(pa.fin_ntiles, pa.ntiles), B), Q_NT, 0, st>>>(c.planes, c.plane_bytes, Wp, c.fflag2, H, W, Wd, ttx, c.spix, x, c.rec,
                                                        c.vlist, out_depth, out_index, status, c.finfo,
-                                                       c.xlist, c.xptr, c.planes + PL_UNRES * c.plane_bytes, vec, ep, c.dscratch, c.rowfar);
+                                                       c.xlist, c.xptr, c.planes + PL_UNRES * c.plane_bytes, vec, ep, c.dscratch, c.rowfar, pa);
             mark();
-            k_tiesx<<<dim3(XL_BLOCKS, B), 256, 0, st>>>(c.planes + PL_UNRES * c.plane_bytes, Wp, c.fflag2, c.finfo, c.xlist,
-                                                        c.xptr, H, W, out_depth, out_index, ep, c.dscratch, c.rowfar);
+            if (fin)
+                k_tiesx<<<dim3(XL_BLOCKS, B), 256, 0, st>>>(c.planes + PL_UNRES * c.plane_bytes, Wp, c.fflag2, c.finfo, c.xlist,
+                                                            c.xptr, H, W, out_depth, out_index, ep, c.dscratch, c.rowfar);
             mark();
         } else {
             mark();
@@ -579,3 +578,12 @@ int dtfill_metrics(const float *output, const float *target, int B, long long n,
 }
 
 }  // extern "C"
+
+#ifdef PTS_PROF
+extern "C" int dtfill_pts_prof(unsigned long long *out8, int reset) {
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pts_prof), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_pts_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

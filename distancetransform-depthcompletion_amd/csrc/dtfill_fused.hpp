@@ -554,23 +554,10 @@ __device__ __forceinline__ void fused_body(bool premarked,
 // sized for the halo-32 tiling (more, smaller tiles); blocks beyond a frame's own tiling exit.  A tile pixel that turns out
 // to be farther than the halo from every source is not stored: its ROW is handed to the any-distance kernels (rowflag,
 // fflag = 1; frame_status), which redo exactly those rows -- the empty sky of a LiDAR frame, a hole in a dense one.
-// the block's LDS: one buffer, carved here for the window kernel and in dtfill_pts.hpp for a k_pts tile
+// the block's LDS: one buffer, carved here
 constexpr size_t F_OFF_RW = (sizeof(u32) * F_RING + 15) & ~(size_t)15, F_OFF_TAB = F_OFF_RW + sizeof(uint2) * F_WHM * 8, F_OFF_ANY = F_OFF_TAB + sizeof(short) * 64,
                  F_LDS_OWN = F_OFF_ANY + sizeof(u32) * 2 * (F_NT / 64);
-constexpr size_t F_LDS = F_LDS_OWN < 39904 ? 39904 : F_LDS_OWN;  // (>= a k_pts block's: checked where that is defined)
-
-struct PtsArgs {  // what a k_pts tile needs beyond the window kernel's own arguments
-    const PtsSrc *ptslist;
-    u32 *xlist, *xptr;
-    u8 *unres;
-    int Wp, tiles_x, ntiles;
-    int tall;  // tiles of 64 x 128 instead of 32 x 256
-};
-template <int TH, int TW>
-__device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, const float *__restrict__ x, const PtsSrc *__restrict__ ptslist, int H,
-                                         int W, int Wp, int tiles_x, const float *__restrict__ vlist, float *__restrict__ out_depth,
-                                         float *__restrict__ out_dt, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
-                                         int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres);
+constexpr size_t F_LDS = F_LDS_OWN;
 
 template <bool STREAM>
 __global__ __launch_bounds__(F_NT, 4) void k_fused(
@@ -578,7 +565,7 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
     int H, int W, int Wd, FusedTiles t16, FusedTiles t32, float *__restrict__ out_depth,
     float *__restrict__ out_dt, int32_t *__restrict__ out_index,
-    const int *__restrict__ route, int *__restrict__ fflag, int *__restrict__ frame_status, const DepthEpilogue ep, const PtsArgs pa) {
+    const int *__restrict__ route, int *__restrict__ fflag, int *__restrict__ frame_status, const DepthEpilogue ep) {
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[F_LDS];
     u32 *s_ring = reinterpret_cast<u32 *>(s_raw);  // later: s_par bytes
     // per window row, the eight image-aligned 32-pixel half words it touches: {source bits, sources before them
@@ -587,16 +574,7 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     short *s_tab = reinterpret_cast<short *>(s_raw + F_OFF_TAB);  // s_par displacement of the step enc (0 for the codes that are no step)
     u32(*s_any)[F_NT / 64] = reinterpret_cast<u32(*)[F_NT / 64]>(s_raw + F_OFF_ANY);  // per wave: did level t produce anything (double-buffered by level parity)
     const int rt = route[blockIdx.y];        // block-uniform
-    if (rt == ROUTE_POINTS) {
-        // a frame with a handful of sources: its 32 x 256 tiles ride in this launch (dtfill_pts.hpp)
-        if ((int)blockIdx.x < pa.ntiles) {
-            if (pa.tall)
-                pts_body<64, 128>(s_raw, x, pa.ptslist, H, W, pa.Wp, pa.tiles_x, vlist, out_depth, out_dt, out_index, frame_status, finfo, pa.xlist, pa.xptr, pa.unres);
-            else
-                pts_body<32, 256>(s_raw, x, pa.ptslist, H, W, pa.Wp, pa.tiles_x, vlist, out_depth, out_dt, out_index, frame_status, finfo, pa.xlist, pa.xptr, pa.unres);
-        }
-        return;
-    }
+    if (rt == ROUTE_POINTS) return;  // a frame with a handful of sources: k_pts's tiles ride in k_fin's launch (dtfill_pts.hpp)
     const int r = rt > 0 ? (rt & 0xFF) : 0;
     const bool pre = rt > 0 && (rt & ROUTE_PREMARK);
     const bool epi = ep.row0 != 0 || ep.use_floor;  // uniform: the plain pass runs code compiled without the epilogue

@@ -1,7 +1,8 @@
 // dtfill_pts.hpp -- pts_body ("k_pts"): l1_cv frames with a handful of sources (the NYU sampling patterns), one kernel from the source
 // list to the three outputs
 // Part of libdtfill.so; included by dtfill.hip inside its anonymous namespace (one translation unit), after dtfill_rows.hpp
-// (the bit-sliced parent rule rule_tap / step_tap and the tile geometry Q_* are k_fin's).
+// (the bit-sliced parent rule rule_tap, the tile geometry Q_* and fin_body, the other half of the k_fin kernel at the end of this
+// file, are defined there).
 #pragma once
 
 // ------------------------------------------------------------------------------------------------
@@ -38,16 +39,27 @@ static_assert(P_WB % P_RC == 0, "whole chunks");
 template <int TH, int TW>
 struct PtsGeom {
     static_assert(TH % 32 == 0 && TW % 64 == 0 && (TH / 32) * (TW / 64) == Q_NT / 64 && TH * (TW / 32) == Q_NT, "four waves, a thread per word");
-    static constexpr int WW = TW / 32, RS = WW + 3, NR = TH + 4, SP = TW + 4, NWC = TW / 64;
-    // LDS of one block, carved from the window kernel's buffer (the tiles of such frames ride in k_fused's launch)
-    static constexpr size_t OFF_BYTE = (sizeof(u32) * 6 * NR * RS + 15) & ~(size_t)15, OFF_SRC = OFF_BYTE + TH * TW,
+    static constexpr int WW = TW / 32, RS = WW + 2, NR = TH + 4, SP = TW + 4, NWC = TW / 64, NPL = 5;
+    // LDS of one block: under 32 KB, five blocks per CU (k_fin's own tiles need less)
+    static constexpr size_t OFF_BYTE = (sizeof(u32) * NPL * NR * RS + 15) & ~(size_t)15, OFF_SRC = OFF_BYTE + sizeof(uint4) * TH * WW,
                             OFF_RC = (OFF_SRC + sizeof(u16) * NR * SP + 3) & ~(size_t)3, OFF_LIST = OFF_RC + sizeof(u32) * PTS_MAX,
                             OFF_CNT = OFF_LIST + Q_NT, LDS = OFF_CNT + sizeof(u32) * (Q_NT / 64);
     static_assert(SP % 2 == 0, "rows of the index array are 4-byte aligned");
-    static_assert(LDS <= F_LDS, "k_fused's buffer holds a k_pts block");
-    static_assert((size_t)TH * TW >= (Q_NT / 64) * PTS_MAX * sizeof(u16), "the candidate lists live in s_byte until the planes are done");
+    static_assert(sizeof(uint4) * TH * WW >= (Q_NT / 64) * PTS_MAX * sizeof(u16), "the candidate lists live in the step codes' place until the planes are done");
+    static_assert(LDS <= 32 * 1024, "five blocks per CU");
 };
 
+#ifdef PTS_PROF  // development probe (scripts/dev/pts_phase_probe.py): cycles per phase, summed over the waves
+__device__ unsigned long long g_pts_prof[12];
+#define PTS_MARK(k_)                                                         \
+    do {                                                                     \
+        const unsigned long long t_ = __builtin_readcyclecounter();          \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_pts_prof[k_], t_ - tprev); \
+        tprev = t_;                                                          \
+    } while (0)
+#else
+#define PTS_MARK(k_)
+#endif
 __device__ __forceinline__ u32 med3u(u32 a, u32 b, u32 c) {
     u32 r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -61,14 +73,17 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                                          int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres) {
     using G = PtsGeom<TH, TW>;
     constexpr int WW = G::WW, RS = G::RS, NR = G::NR, SP = G::SP, NWC = G::NWC;
-    u32(*s_pl)[NR][RS] = reinterpret_cast<u32(*)[NR][RS]>(s_raw);      // d bit 0, 1, 2, live, tie, in-image; rows r0-2 .. r0+TH+1; word 0 / WW+1: the ring's
-    u8(*s_byte)[TW] = reinterpret_cast<u8(*)[TW]>(s_raw + G::OFF_BYTE);  // per tile pixel: step to its parent; before that: the waves' candidate lists
+    u32(*s_pl)[NR][RS] = reinterpret_cast<u32(*)[NR][RS]>(s_raw);      // d bit 0, 1, 2, live, tie; rows r0-2 .. r0+TH+1; word 0 / WW+1: the ring's
+    uint4 *s_code = reinterpret_cast<uint4 *>(s_raw + G::OFF_BYTE);      // per tile word: the four bit planes of its tie pixels' tap codes (tap_decode); before that: the waves' candidate lists
     u16(*s_src)[SP] = reinterpret_cast<u16(*)[SP]>(s_raw + G::OFF_SRC);  // per box pixel: list index of its nearest source | plane bits << 9
     u32 *s_rc = reinterpret_cast<u32 *>(s_raw + G::OFF_RC);              // the frame's sources: row << 16 | column; later their depths
     u8 *s_list = s_raw + G::OFF_LIST;                                     // the listed words (phase 4)
     u32 *s_cnt = reinterpret_cast<u32 *>(s_raw + G::OFF_CNT);
     const int b = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PTS_PROF
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * TH, c0 = tx * TW;
     const int wr = wave / NWC, wcol = wave - wr * NWC;  // the wave's place in the tile
@@ -146,24 +161,24 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
             __builtin_amdgcn_wave_barrier();
         }
     }
+    PTS_MARK(0);
+#ifdef PTS_PROF
+    if (lane == 0 && !wave_idle) {
+        atomicAdd(&g_pts_prof[8], 1ull);
+        atomicAdd(&g_pts_prof[9], (unsigned long long)nw);
+        atomicAdd(&g_pts_prof[10], (unsigned long long)nw * nw);
+        atomicMax(&g_pts_prof[11], (unsigned long long)nw);
+    }
+#endif
     // ---- 3. per pixel: the minima over the wave's candidates.  Lane = column wc0 + lane, P_RC rows at a time in registers.
     //   K1 = the smallest key d << 15 | index << 6 | position, M2 = the second smallest (v_med3 of the two and the newcomer): one nearest
     //   source iff their distances differ; K3 over the candidates at or above the row: the list is in raster order, so those
     //   are a prefix of it -- all rows of a chunk share the candidates above its first row (no test), none has those below its
     //   last row (no K3 at all), only the few inside the chunk's rows are tested row by row.
     const int nval = finfo[b * FI_STRIDE + FI_NVAL], misaligned = finfo[b * FI_STRIDE + FI_MISALIGNED];
-    const float *vl_f = vlist + fo;
     float *dt_f = out_dt ? out_dt + fo : nullptr, *dp_f = out_depth ? out_depth + fo : nullptr;
     int32_t *ix_f = out_index ? out_index + fo : nullptr;
     bool bad = false;
-    auto depth_of = [&](u32 idx, bool want) -> float {  // depth_list[label - 1] (tools.py:26) for label = idx + 1
-        if (misaligned) {  // block-uniform; rare
-            const bool oob = (int)idx >= nval;
-            bad |= want && oob;
-            return oob ? nanf("") : vl_f[idx];
-        }
-        return sl[min(idx, (u32)(PTS_MAX - 1))].v;  // masks agree: the label-th value IS the source pixel's own depth
-    };
     {
         const int j = wc0 + lane;
         const bool jin = j < W;
@@ -174,7 +189,12 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
             constexpr bool FAST = decltype(fast_t)::value;
             const u32 myidx = lane < nw ? (u32)wc[lane] : 0u;
             const u32 myrc = s_rc[myidx];
-            const float myval = (FAST && dp_f && !misaligned && lane < nw) ? sl[myidx].v : 0.0f;
+            // the depth goes out with the label when it can come from the candidates' registers: not from a list of more than
+            // 64, not when the masks disagree (depth_list is then not the sources' own values) -- those waves' pixels take
+            // theirs from the depth list in LDS once the tile's planes are done (below)
+            const bool depth_now = FAST && dp_f && !misaligned;
+            const float myval = (depth_now && lane < nw) ? sl[myidx].v : 0.0f;
+            const int j3 = 3 * j;
             for (int rb = 0; rb < P_WB; rb += P_RC) {
                 u32 K1[P_RC], M2[P_RC], K3[P_RC];
 #pragma unroll
@@ -220,23 +240,24 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
 #pragma unroll
                 for (int u = 0; u < P_RC; ++u) {
                     const int row = rb + u, i = ib + u;  // wave-uniform
-                    const bool rin = i >= 0 && i < H;
-                    const u32 d = K1[u] >> 15, i1 = (K1[u] >> 6) & 511u, pos = K1[u] & 63u;
-                    const bool tie = ((M2[u] >> 15) == d) & (d != 0u);
-                    const bool live = ((K3[u] >> 13) == d) & (3 * (int)(K3[u] & 8191u) <= (int)(2u * d) + 3 * j);
+                    const bool rin = (unsigned)i < (unsigned)H;
+                    const u32 k1 = K1[u], k3 = K3[u], d = k1 >> 15;
+                    // (a source pixel, d = 0, is no tie pixel: no second source shares its pixel, M2's distance is larger)
+                    const bool tie = (M2[u] >> 15) == d;
+                    const bool live = ((k3 >> 13) == d) & (3 * (int)(k3 & 8191u) <= (int)(2u * d) + j3);
                     // the pixel's plane bits ride with its index: d mod 8 | live << 3 | tie << 4 | in-image << 5 (all zero outside)
-                    const u32 code = (rin && jin) ? ((d & 7u) | (live ? 8u : 0u) | (tie ? 16u : 0u) | 32u) : 0u;
-                    s_src[32 * wr + row][2 + 64 * wcol + lane] = (u16)(i1 | code << 9);
-                    if (row >= 2 && row < 34) {  // the wave's own 32 rows
+                    u32 sv = 0u;
+                    if (rin) sv = jin ? (((k1 >> 6) & 511u) | ((d & 7u) | (live ? 8u : 0u) | (tie ? 16u : 0u) | 32u) << 9) : 0u;
+                    s_src[32 * wr + row][2 + 64 * wcol + lane] = (u16)sv;
+                    if (rin && row >= 2 && row < 34) {  // the wave's own 32 rows
                         // the tile's own pixels: the distance now; label and depth too unless a chain has to be followed (phase 4)
-                        float val = 0.0f;
-                        if (dp_f) val = (FAST && !misaligned) ? __shfl(myval, (int)pos) : 0.0f;
-                        if (rin && jin) {
+                        const float val = depth_now ? __shfl(myval, (int)(k1 & 63u)) : 0.0f;
+                        if (jin) {
                             const u32 ob = (u32)(__umul24((u32)i, (u32)W) + (u32)j) << 2;
                             if (dt_f) st_off_nt(dt_f, ob, (float)d);
                             if (!tie) {
-                                if (ix_f) st_off_nt(ix_f, ob, (int32_t)i1 + 1);
-                                if (dp_f) st_off_nt(dp_f, ob, (FAST && !misaligned) ? val : depth_of(i1, true));
+                                if (ix_f) st_off_nt(ix_f, ob, (int32_t)((k1 >> 6) & 511u) + 1);
+                                if (depth_now) st_off_nt(dp_f, ob, val);
                             }
                         }
                     }
@@ -283,7 +304,8 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
           }
         }
     }
-    __syncthreads();  // every box pixel's index and plane bits are in s_src; the candidate lists (in s_byte) are dead
+    PTS_MARK(1);
+    __syncthreads();  // every box pixel's index and plane bits are in s_src; the candidate lists (in s_code's place) are dead
     // from here on s_rc holds depth_list[k] instead of the sources' positions (phase 4 looks depths up there)
     {
         const int nvl = finfo[b * FI_STRIDE + FI_NVAL], mis = finfo[b * FI_STRIDE + FI_MISALIGNED];
@@ -296,16 +318,20 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
     // ---- the bit planes k_fin's rule reads, 32 pixels per word: a thread per (box row, word) gathers bit p of 32 codes
     for (int it = tid; it < NR * (WW + 2); it += Q_NT) {
         const int row = it / (WW + 2), w = it - row * (WW + 2);  // word 0 / WW + 1: the ring's (two pixels each)
-        u32 pl[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        u32 pl[5] = {0u, 0u, 0u, 0u, 0u};  // (bit 5 of a code, "in the image", follows from the geometry: inw() below)
         if (w >= 1 && w <= WW) {
+            const u32 *q4 = reinterpret_cast<const u32 *>(&s_src[row][2 + 32 * (w - 1)]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const u32 *q4 = reinterpret_cast<const u32 *>(&s_src[row][2 + 32 * (w - 1) + 8 * g]);
+            for (int g = 0; g < 8; ++g) {
+                // four pixels: the high bytes of their entries side by side (code bit p is bit 1 + p of a byte), then per plane the
+                // four bits 8 apart are folded next to each other (y | y << 7, | << 14: bits 21 .. 24 of the shifted word)
+                const u32 X = __builtin_amdgcn_perm(q4[2 * g + 1], q4[2 * g], 0x07050301u);
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const u32 v = q4[h];  // two pixels: bits 9..14 and 25..30
-#pragma unroll
-                    for (int p = 0; p < 6; ++p) pl[p] |= (((v >> (9 + p)) & 1u) | ((v >> (24 + p)) & 2u)) << (8 * g + 2 * h);
+                for (int p = 0; p < 5; ++p) {
+                    u32 y = X & (0x01010101u << (1 + p));
+                    y |= y << 7;
+                    y |= y << 14;
+                    pl[p] |= ((y >> (22 + p)) & 15u) << (4 * g);
                 }
             }
         } else {
@@ -314,13 +340,30 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
             for (int e = 0; e < 2; ++e) {
                 const u32 v = s_src[row][cb + e];
 #pragma unroll
-                for (int p = 0; p < 6; ++p) pl[p] |= ((v >> (9 + p)) & 1u) << (sh + e);
+                for (int p = 0; p < 5; ++p) pl[p] |= ((v >> (9 + p)) & 1u) << (sh + e);
             }
         }
 #pragma unroll
-        for (int p = 0; p < 6; ++p) s_pl[p][row][w] = pl[p];
+        for (int p = 0; p < 5; ++p) s_pl[p][row][w] = pl[p];
     }
+    PTS_MARK(2);
     __syncthreads();
+    PTS_MARK(3);
+    // the depths phase 3 left out (see depth_now there): depth_list[label - 1] (tools.py:26) from LDS, for the wave's pixels that
+    // are no tie pixels (those follow their chain below)
+    if (dp_f && !wave_idle && (misaligned || nw > 64)) {  // wave-uniform
+        const int j = wc0 + lane;
+        for (int row = 0; row < 32; ++row) {
+            const int i = r0w + row;
+            if (i >= H) break;
+            const u32 v = s_src[32 * wr + row + 2][2 + 64 * wcol + lane];
+            if (j < W && !((v >> 13) & 1u)) {
+                const u32 idx = v & 511u;
+                bad |= misaligned && (int)idx >= nval;  // (the list holds NaN there)
+                dp_f[i * W + j] = __uint_as_float(s_rc[idx]);
+            }
+        }
+    }
     // ---- 4. the tie pixels: the tile's 32-pixel words that hold one are listed, one thread per listed word (the words
     // without one -- most, in a frame with a handful of sources -- cost nothing, and whole waves drop out): k_fin's bit-sliced
     // parent rule, step bytes, hops
@@ -355,8 +398,18 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
     if (any_tie) {
         if (mytie) {
             u32 C[4] = {0, 0, 0, 0};
-            u32 E[6] = {0, ~0u, 0, 0, ~0u, 0};
+            // the pixels of box row `row`, plane word `widx` that lie inside the image (word 0 is the left ring's: columns c0 - 32 ..)
+            auto inw = [&](int row, int widx) -> u32 {
+                const int i = r0 - 2 + row, j0 = c0 - 32 + 32 * widx;  // the word's first column
+                if (i < 0 || i >= H) return 0u;
+                const int lo = max(-j0, 0), up = min(W - j0, 32);
+                return up <= lo ? 0u : (up >= 32 ? 0xFFFFFFFFu : ((1u << up) - 1u)) & ~((1u << lo) - 1u);
+            };
             auto ld3 = [&](int p, int row, u32 (&o)[3]) {
+                if (p == 5) {
+                    o[0] = inw(row, tw); o[1] = inw(row, tw + 1); o[2] = inw(row, tw + 2);
+                    return;
+                }
                 const u32 *q3 = &s_pl[p][row][tw];
                 o[0] = q3[0]; o[1] = q3[1]; o[2] = q3[2];
             };
@@ -387,26 +440,16 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
             rule_tap<-1, 2, false, 8 | 5>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
             rule_tap<-2, 3, false, 8 | 6>(a0, a1, a2, lv, vd, b0, b1, b2, takenB, C);
             rule_tap<+1, 1, false, 8 | 7>(z0, z1, z2, lv, zv, b0, b1, b2, takenB, C);
-            E[1] = E[4] = ~mytie;
-            step_tap<0>(C, mytie, E); step_tap<1>(C, mytie, E); step_tap<2>(C, mytie, E); step_tap<3>(C, mytie, E);
-            step_tap<4>(C, mytie, E); step_tap<5>(C, mytie, E); step_tap<6>(C, mytie, E); step_tap<7>(C, mytie, E);
-            step_tap<8>(C, mytie, E); step_tap<9>(C, mytie, E); step_tap<10>(C, mytie, E); step_tap<11>(C, mytie, E);
-            step_tap<12>(C, mytie, E); step_tap<13>(C, mytie, E); step_tap<14>(C, mytie, E); step_tap<15>(C, mytie, E);
-            // only tie pixels' bytes are ever read (a chain stops on the first pixel that is none): words without one write nothing
-            u32 *brow = reinterpret_cast<u32 *>(&s_byte[trow][tw * 32]);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                u32 v = 0;
-#pragma unroll
-                for (int jq = 0; jq < 6; ++jq) v |= (mul_u24_opaque((E[jq] >> (4 * g)) & 0xFu, 0x00204081u) & 0x01010101u) << jq;
-                brow[g] = v;
-            }
+            // the tap codes stay bit-sliced: a hop reads its four bits out of the word's planes (only tie pixels' codes are ever
+            // read: a chain stops on the first pixel that is none)
+            s_code[trow * WW + tw] = make_uint4(C[0], C[1], C[2], C[3]);
         }
+        PTS_MARK(4);
         __syncthreads();
-        // every tie pixel of this word hops along the step bytes until it stands on a pixel that is no tie pixel and takes that
+        // every tie pixel of this word hops along the tap codes until it stands on a pixel that is no tie pixel and takes that
         // pixel's source; a chain that leaves the tile while still on tie pixels, or runs longer than Q_HOPS, goes to k_tiesx
         auto is_tie = [&](int r, int c) -> bool { return (s_pl[4][r + 2][(c + 32) >> 5] >> ((c + 32) & 31)) & 1u; };
-        u32 m = mytie & s_pl[5][trow + 2][tw + 1];
+        u32 m = mytie;  // (a tie bit is only ever set inside the image)
         while (m) {
             const int bit = __ffs((int)m) - 1;
             m &= m - 1;
@@ -415,9 +458,12 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
             bool open = true;
             for (int hop = 0; hop < Q_HOPS; ++hop) {
                 if (er < 0 || er >= TH || ec < 0 || ec >= TW) break;  // a tie pixel of another tile: no step here
-                const u32 bb = s_byte[er][ec] & 63u;
-                er += (int)(bb >> 3) - 2;
-                ec += (int)(bb & 7u) - 2;
+                const uint4 cw4 = s_code[er * WW + (ec >> 5)];
+                const int sb = ec & 31;
+                int di, dj;
+                tap_decode((int)(((cw4.x >> sb) & 1u) | ((cw4.y >> sb) & 1u) << 1 | ((cw4.z >> sb) & 1u) << 2 | ((cw4.w >> sb) & 1u) << 3), di, dj);
+                er += di;
+                ec += dj;
                 if (!is_tie(er, ec)) {
                     open = false;
                     break;
@@ -435,6 +481,7 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                 if (dp_f) dp_f[pix] = __uint_as_float(s_rc[idx]);
             }
         }
+        PTS_MARK(5);
         // the handed-on pixels join the frame's list: block-wide count, ONE atomic, then every thread writes its own
         const int cu = __popc(umask);
         int incl = cu;
@@ -465,5 +512,43 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
         }
     }
     if (tin) reinterpret_cast<u32 *>(unres + ((size_t)b * H + gi) * Wp)[gw] = umask;
+    PTS_MARK(6);
     if (bad && out_depth) atomicOr(frame_status + b, DTFILL_FRAME_INDEX_ERROR);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The k_fin launch: a block is a tile of fin_body (frames on the any-distance path: fflag 1 / 2) or a tile of pts_body (fflag 3).
+// One buffer of LDS, carved by either; 32 KB and 92 registers keep five blocks on a CU.
+// ------------------------------------------------------------------------------------------------
+struct PtsArgs {  // what a k_pts tile needs beyond fin_body's arguments
+    const PtsSrc *ptslist;
+    float *out_dt;
+    int tiles_x, ntiles;
+    int tall;        // tiles of 64 x 128 instead of 32 x 256
+    int fin_ntiles;  // fin_body's tiles (0: neither depth nor labels are wanted, the launch is k_pts's alone)
+};
+constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
+constexpr size_t FIN_LDS = cmax(FIN_LDS_OWN, cmax(PtsGeom<32, 256>::LDS, PtsGeom<64, 128>::LDS));
+static_assert(FIN_LDS <= 32 * 1024, "five blocks per CU");
+
+__global__ __launch_bounds__(Q_NT, 4) void k_fin(
+    const u8 *__restrict__ planes, size_t plane_bytes, int Wp, const int *__restrict__ fflag, int H, int W, int Wd,
+    int tiles_x, const u32 *__restrict__ spix_ws, const float *__restrict__ x, const uint4 *__restrict__ rec,
+    const float *__restrict__ vlist,
+    float *__restrict__ out_depth, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
+    int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres, int vec,
+    const DepthEpilogue ep, float *__restrict__ dscratch, const u32 *__restrict__ rowflag, const PtsArgs pa) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[FIN_LDS];
+    if (fflag[blockIdx.y] == 3) {  // (block-uniform)
+        if ((int)blockIdx.x < pa.ntiles) {
+            if (pa.tall)
+                pts_body<64, 128>(s_raw, x, pa.ptslist, H, W, Wp, pa.tiles_x, vlist, out_depth, pa.out_dt, out_index, frame_status, finfo, xlist, xptr, unres);
+            else
+                pts_body<32, 256>(s_raw, x, pa.ptslist, H, W, Wp, pa.tiles_x, vlist, out_depth, pa.out_dt, out_index, frame_status, finfo, xlist, xptr, unres);
+        }
+        return;
+    }
+    if ((int)blockIdx.x < pa.fin_ntiles)
+        fin_body(s_raw, planes, plane_bytes, Wp, fflag, H, W, Wd, tiles_x, spix_ws, x, rec, vlist, out_depth, out_index, frame_status, finfo, xlist, xptr,
+                 unres, vec, ep, dscratch, rowflag);
 }

@@ -543,20 +543,26 @@ __device__ __forceinline__ void step_tap(const u32 (&C)[4], u32 mytie, u32 (&E)[
         if (ENC & (1 << j)) E[j] |= sel;
 }
 
-__global__ __launch_bounds__(Q_NT, 4) void k_fin(
+// LDS of a k_fin block (carved from the kernel's buffer: the kernel, in dtfill_pts.hpp, also runs k_pts's tiles)
+constexpr size_t FIN_OFF_BYTE = sizeof(u32) * 6 * (Q_TH + 4) * Q_RS, FIN_OFF_UNRES = FIN_OFF_BYTE + Q_TH * Q_TW,
+                 FIN_OFF_CNT = FIN_OFF_UNRES + sizeof(u32) * Q_NT, FIN_LDS_OWN = FIN_OFF_CNT + sizeof(u32) * (Q_NT / 64);
+static_assert(FIN_OFF_BYTE % 4 == 0, "the step bytes are read as words");
+
+__device__ __forceinline__ void fin_body(
+    unsigned char *__restrict__ s_raw,
     const u8 *__restrict__ planes, size_t plane_bytes, int Wp, const int *__restrict__ fflag, int H, int W, int Wd,
     int tiles_x, const u32 *__restrict__ spix_ws, const float *__restrict__ x, const uint4 *__restrict__ rec,
     const float *__restrict__ vlist,
     float *__restrict__ out_depth, int32_t *__restrict__ out_index, int *__restrict__ frame_status,
     int *__restrict__ finfo, u32 *__restrict__ xlist, u32 *__restrict__ xptr, u8 *__restrict__ unres, int vec,
     const DepthEpilogue ep, float *__restrict__ dscratch, const u32 *__restrict__ rowflag) {
-    __shared__ u32 s_pl[6][Q_TH + 4][Q_RS];  // d bit 0, 1, 2, live, tie, in-image; rows r0-2 .. r0+TH+1
-    __shared__ u8 s_byte[Q_TH][Q_TW];   // per tile pixel: step to its parent ((di + 2) << 3 | (dj + 2); 18 = none)
-    __shared__ u32 s_unres[Q_NT];       // per tile word: tie pixels that k_tiesx finishes
-    __shared__ u32 s_cnt[Q_NT / 64];
+    u32(*s_pl)[Q_TH + 4][Q_RS] = reinterpret_cast<u32(*)[Q_TH + 4][Q_RS]>(s_raw);  // d bit 0, 1, 2, live, tie, in-image; rows r0-2 .. r0+TH+1
+    u8(*s_byte)[Q_TW] = reinterpret_cast<u8(*)[Q_TW]>(s_raw + FIN_OFF_BYTE);  // per tile pixel: step to its parent ((di + 2) << 3 | (dj + 2); 18 = none)
+    u32 *s_unres = reinterpret_cast<u32 *>(s_raw + FIN_OFF_UNRES);            // per tile word: tie pixels that k_tiesx finishes
+    u32 *s_cnt = reinterpret_cast<u32 *>(s_raw + FIN_OFF_CNT);
     const int b = blockIdx.y, tid = threadIdx.x;
     const int ff = fflag[b];
-    if (!ff || ff == 3) return;  // 3: k_pts's frame
+    if (!ff) return;  // (3, k_pts's frame: the kernel has taken that turn)
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int r0 = ty * Q_TH, c0 = tx * Q_TW;
     // the tile's rows that are redone: all of them, or (ff == 1) those k_fused marked; the others keep k_fused's results
@@ -611,7 +617,14 @@ __global__ __launch_bounds__(Q_NT, 4) void k_fin(
     __syncthreads();
     const u32 mytie = s_pl[4][trow + 2][tw + 1];
     s_unres[tid] = 0;
-    const bool any_tie = __syncthreads_or(mytie != 0);  // block-uniform: some tie pixel in this tile
+    // block-uniform: some tie pixel in this tile (a word per wave: __syncthreads_or would take 256 bytes of LDS of its own, the
+    // sixth of five blocks' worth on a CU)
+    if ((tid & 63) == 0) s_cnt[tid >> 6] = 0;
+    if (mytie) s_cnt[tid >> 6] = 1;  // (same-wave stores to one address: any of them lands)
+    __syncthreads();
+    bool any_tie = false;
+#pragma unroll
+    for (int w = 0; w < Q_NT / 64; ++w) any_tie = any_tie || s_cnt[w] != 0;
     if (any_tie) {
         u32 C[4] = {0, 0, 0, 0};
         u32 E[6] = {0, ~0u, 0, 0, ~0u, 0};  // bit planes of the step code (di + 2) << 3 | (dj + 2); 18 = (0, 0) where no tie pixel
