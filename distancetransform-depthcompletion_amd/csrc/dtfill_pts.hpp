@@ -208,46 +208,89 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                     nA += __popcll(__ballot(sr <= ib));
                     nB += __popcll(__ballot(sr <= ib + P_RC - 1));
                 }
-                auto body = [&](int c, auto mode) {
-                    // the low 15 bits of the keys: list index << 6 | position in the wave's list (FAST; both in the list's order)
-                    u32 idx, rc;
-                    if (FAST) {
-                        idx = (u32)__builtin_amdgcn_readlane((int)myidx, c) << 6 | (u32)c;
-                        rc = (u32)__builtin_amdgcn_readlane((int)myrc, c);
-                    } else {
-                        idx = (u32)__builtin_amdgcn_readfirstlane((int)wc[c]);
-                        rc = (u32)__builtin_amdgcn_readfirstlane((int)s_rc[idx]);
-                        idx <<= 6;
+                if constexpr (FAST) {
+                    // keys d << 19 | column << 6 | position in the wave's list.  A column of pixels sees a source above it one farther
+                    // per row down: the minimum (and the second smallest) over the sources at or above the chunk's first row is taken
+                    // ONCE, on that row, and goes down the chunk by adding 1 << 19 per row; likewise upwards from the chunk's last row
+                    // for the sources below it.  Only the sources on the chunk's own rows meet every row one by one.  The "down"
+                    // minimum is K3 as it stands: its ties go to the smaller column.
+                    u32 kd = 0xFFFFFFFFu, md = 0xFFFFFFFFu, ku = 0xFFFFFFFFu, mu = 0xFFFFFFFFu;
+                    const u32 qe = qb + ((u32)(P_RC - 1) << 16);
+                    for (int c = 0; c < nA; ++c) {
+                        const u32 rc = (u32)__builtin_amdgcn_readlane((int)myrc, c);
+                        const u32 key = __builtin_amdgcn_sad_u16(qb, rc + (4u << 16 | 4u), 0u) << 19 | ((rc & 0xFFFFu) << 6 | (u32)c);
+                        md = med3u(kd, md, key);
+                        kd = min(kd, key);
                     }
-                    const u32 sp = rc + (4u << 16 | 4u), colkey = rc & 0xFFFFu;
-                    const int sr = (int)(rc >> 16);
+                    for (int c = nB; c < nw; ++c) {
+                        const u32 rc = (u32)__builtin_amdgcn_readlane((int)myrc, c);
+                        const u32 key = __builtin_amdgcn_sad_u16(qe, rc + (4u << 16 | 4u), 0u) << 19 | ((rc & 0xFFFFu) << 6 | (u32)c);
+                        mu = med3u(ku, mu, key);
+                        ku = min(ku, key);
+                    }
 #pragma unroll
                     for (int u = 0; u < P_RC; ++u) {
-                        const u32 d = __builtin_amdgcn_sad_u16(qb + ((u32)u << 16), sp, 0u);
-                        const u32 key = d << 15 | idx;
-                        M2[u] = med3u(K1[u], M2[u], key);  // K1 <= M2: the second smallest of the three
-                        K1[u] = min(K1[u], key);
-                        if (decltype(mode)::value == 0) {
-                            K3[u] = min(K3[u], d << 13 | colkey);
-                        } else if (decltype(mode)::value == 1) {
-                            if (sr <= ib + u) K3[u] = min(K3[u], d << 13 | colkey);  // wave-uniform
+                        // (saturating: "no such source" stays what it is)
+                        const u32 a = __builtin_elementwise_add_sat(kd, (u32)u << 19), a2 = __builtin_elementwise_add_sat(md, (u32)u << 19);
+                        const u32 e = __builtin_elementwise_add_sat(ku, (u32)(P_RC - 1 - u) << 19),
+                                  e2 = __builtin_elementwise_add_sat(mu, (u32)(P_RC - 1 - u) << 19);
+                        K1[u] = min(a, e);
+                        M2[u] = min(min(max(a, e), a2), e2);
+                        K3[u] = a;
+                    }
+                    for (int c = nA; c < nB; ++c) {
+                        const u32 rc = (u32)__builtin_amdgcn_readlane((int)myrc, c);
+                        const u32 sp = rc + (4u << 16 | 4u), low = (rc & 0xFFFFu) << 6 | (u32)c;
+                        const int sr = (int)(rc >> 16);
+#pragma unroll
+                        for (int u = 0; u < P_RC; ++u) {
+                            const u32 key = __builtin_amdgcn_sad_u16(qb + ((u32)u << 16), sp, 0u) << 19 | low;
+                            M2[u] = med3u(K1[u], M2[u], key);
+                            K1[u] = min(K1[u], key);
+                            if (sr <= ib + u) K3[u] = min(K3[u], key);  // wave-uniform
                         }
                     }
-                };
-                for (int c = 0; c < nA; ++c) body(c, std::integral_constant<int, 0>{});
-                for (int c = nA; c < nB; ++c) body(c, std::integral_constant<int, 1>{});
-                for (int c = nB; c < nw; ++c) body(c, std::integral_constant<int, 2>{});
+                } else {
+                    auto body = [&](int c, auto mode) {
+                        // the low 15 bits of the keys: list index << 6
+                        u32 idx = (u32)__builtin_amdgcn_readfirstlane((int)wc[c]);
+                        const u32 rc = (u32)__builtin_amdgcn_readfirstlane((int)s_rc[idx]);
+                        idx <<= 6;
+                        const u32 sp = rc + (4u << 16 | 4u), colkey = rc & 0xFFFFu;
+                        const int sr = (int)(rc >> 16);
+#pragma unroll
+                        for (int u = 0; u < P_RC; ++u) {
+                            const u32 d = __builtin_amdgcn_sad_u16(qb + ((u32)u << 16), sp, 0u);
+                            const u32 key = d << 15 | idx;
+                            M2[u] = med3u(K1[u], M2[u], key);  // K1 <= M2: the second smallest of the three
+                            K1[u] = min(K1[u], key);
+                            if (decltype(mode)::value == 0) {
+                                K3[u] = min(K3[u], d << 13 | colkey);
+                            } else if (decltype(mode)::value == 1) {
+                                if (sr <= ib + u) K3[u] = min(K3[u], d << 13 | colkey);  // wave-uniform
+                            }
+                        }
+                    };
+                    for (int c = 0; c < nA; ++c) body(c, std::integral_constant<int, 0>{});
+                    for (int c = nA; c < nB; ++c) body(c, std::integral_constant<int, 1>{});
+                    for (int c = nB; c < nw; ++c) body(c, std::integral_constant<int, 2>{});
+                }
 #pragma unroll
                 for (int u = 0; u < P_RC; ++u) {
                     const int row = rb + u, i = ib + u;  // wave-uniform
                     const bool rin = (unsigned)i < (unsigned)H;
-                    const u32 k1 = K1[u], k3 = K3[u], d = k1 >> 15;
+                    const u32 k1 = K1[u], k3 = K3[u];
+                    constexpr int DS = FAST ? 19 : 15;  // the distance's place in the keys
+                    const u32 d = k1 >> DS;
                     // (a source pixel, d = 0, is no tie pixel: no second source shares its pixel, M2's distance is larger)
-                    const bool tie = (M2[u] >> 15) == d;
-                    const bool live = ((k3 >> 13) == d) & (3 * (int)(k3 & 8191u) <= (int)(2u * d) + j3);
+                    const bool tie = (M2[u] >> DS) == d;
+                    const u32 col3 = FAST ? (k3 >> 6) & 8191u : k3 & 8191u;
+                    const bool live = ((k3 >> (FAST ? 19 : 13)) == d) & (3 * (int)col3 <= (int)(2u * d) + j3);
+                    // the winner's list index: in the key, or with the candidate in lane k1 & 63
+                    const u32 i1 = FAST ? (u32)__shfl((int)myidx, (int)(k1 & 63u)) : (k1 >> 6) & 511u;
                     // the pixel's plane bits ride with its index: d mod 8 | live << 3 | tie << 4 | in-image << 5 (all zero outside)
                     u32 sv = 0u;
-                    if (rin) sv = jin ? (((k1 >> 6) & 511u) | ((d & 7u) | (live ? 8u : 0u) | (tie ? 16u : 0u) | 32u) << 9) : 0u;
+                    if (rin) sv = jin ? (i1 | ((d & 7u) | (live ? 8u : 0u) | (tie ? 16u : 0u) | 32u) << 9) : 0u;
                     s_src[32 * wr + row][2 + 64 * wcol + lane] = (u16)sv;
                     if (rin && row >= 2 && row < 34) {  // the wave's own 32 rows
                         // the tile's own pixels: the distance now; label and depth too unless a chain has to be followed (phase 4)
@@ -256,7 +299,7 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                             const u32 ob = (u32)(__umul24((u32)i, (u32)W) + (u32)j) << 2;
                             if (dt_f) st_off_nt(dt_f, ob, (float)d);
                             if (!tie) {
-                                if (ix_f) st_off_nt(ix_f, ob, (int32_t)((k1 >> 6) & 511u) + 1);
+                                if (ix_f) st_off_nt(ix_f, ob, (int32_t)i1 + 1);
                                 if (depth_now) st_off_nt(dp_f, ob, val);
                             }
                         }
@@ -267,7 +310,7 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
         if (wave_idle) {
             // no plane bits: outside the image.  (Its first four rows are the last four of the wave above, which writes them.)
             for (int row = wr ? 4 : 0; row < P_WB; ++row) s_src[32 * wr + row][2 + 64 * wcol + lane] = 0;
-        } else if (nw <= 64)
+        } else if (nw <= 64 && H + W <= 8100)  // (13 bits of distance, 13 of column in the fast keys)
             run(std::true_type{});
         else
             run(std::false_type{});
@@ -351,7 +394,7 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
     PTS_MARK(3);
     // the depths phase 3 left out (see depth_now there): depth_list[label - 1] (tools.py:26) from LDS, for the wave's pixels that
     // are no tie pixels (those follow their chain below)
-    if (dp_f && !wave_idle && (misaligned || nw > 64)) {  // wave-uniform
+    if (dp_f && !wave_idle && (misaligned || nw > 64 || H + W > 8100)) {  // wave-uniform
         const int j = wc0 + lane;
         for (int row = 0; row < 32; ++row) {
             const int i = r0w + row;
