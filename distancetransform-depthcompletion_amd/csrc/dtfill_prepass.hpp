@@ -426,27 +426,30 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         PtsSrc *list = ptslist + (size_t)b * L2_PTS_MAX;
         const float *xf = x + (size_t)b * H * W;
         // an item = one 64-pixel word of a row that holds a source (the rows were listed above); a word's sources go to their
-        // raster ranks; two items per step (independent loads)
+        // raster ranks.  Four items per step, and everything an item needs before its depths is loaded at once (this block alone
+        // works on the frame: the chain of dependent loads is what the step costs)
+        constexpr int NQ = 4;
         const int nitems = min(s_nrow, L2_PTS_MAX) * Wd;
-        for (int it0 = tid; it0 < nitems; it0 += 512) {
-            u64 sb[2];
-            int row[2], w[2];
+        for (int it0 = tid; it0 < nitems; it0 += 256 * NQ) {
+            u64 sb[NQ];
+            u32 k[NQ];
+            int row[NQ], w[NQ];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int it = it0 + 256 * q;
-                row[q] = s_ptrow[min(it, nitems - 1) / Wd];
-                w[q] = min(it, nitems - 1) % Wd;
-                sb[q] = it < nitems ? srcbits[((size_t)b * H + row[q]) * Wd + w[q]] : 0ull;
+            for (int q = 0; q < NQ; ++q) {
+                const int it = min(it0 + 256 * q, nitems - 1);
+                row[q] = s_ptrow[it / Wd];
+                w[q] = it % Wd;
+                const size_t at = ((size_t)b * H + row[q]) * Wd + w[q];
+                sb[q] = it0 + 256 * q < nitems ? srcbits[at] : 0ull;
+                k[q] = bs_[row[q]] + wpre_s[at];  // (this block wrote bs_ above, before a barrier)
             }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 u64 m = sb[q];
-                if (!m) continue;
-                u32 k = bs_[row[q]] + wpre_s[((size_t)b * H + row[q]) * Wd + w[q]];  // (this block wrote bs_ above, before a barrier)
                 while (m) {
                     const int j = w[q] * 64 + __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    list[k++] = PtsSrc{(u32)row[q] << 16 | (u32)j, xf[(size_t)row[q] * W + j]};  // ... with its depth
+                    list[k[q]++] = PtsSrc{(u32)row[q] << 16 | (u32)j, xf[(size_t)row[q] * W + j]};  // ... with its depth
                 }
             }
         }
