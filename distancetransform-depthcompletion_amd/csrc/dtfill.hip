@@ -473,10 +473,12 @@ int dtfill_generate_multi_channel(const float *data, const float *mask, int B, i
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float *src = data, *msk = mask;
     for (int k = 0; k < scale_num - 1; ++k) {
+        // (table size 7: a step also writes the later steps' values of the pixels that will pass their masks)
+        float *n1 = k + 1 < scale_num - 1 ? outs[k + 1] : nullptr, *n2 = k + 2 < scale_num - 1 ? outs[k + 2] : nullptr;
         if (table_size == 7 && msk)
-            k_gmc7<false><<<grid, 256, 0, st>>>(src, msk, H, W, outs[k]);
+            k_gmc7<false><<<grid, 256, 0, st>>>(src, msk, H, W, outs[k], n1, n2);
         else if (table_size == 7)
-            k_gmc7<true><<<grid, 256, 0, st>>>(src, nullptr, H, W, outs[k]);
+            k_gmc7<true><<<grid, 256, 0, st>>>(src, nullptr, H, W, outs[k], n1, n2);
         else
             k_gmc<<<grid, 256, lds, st>>>(src, msk, H, W, table_size, outs[k]);
         src = outs[k];

@@ -15,10 +15,25 @@ constexpr int GM_TH = 16, GM_TW = 64, GM_MAXHALF = 7;
 // maximum restarts sum and count, an equal value extends them -- the additions performed are exactly "sum
 // over the selected taps in tap order", as in the two-pass form below.  DERIVED: the mask is data > 0.001
 // (steps 2 and 3), so only the data tile is staged.
+//
+// A pixel whose own value passes the next step's mask (v > 0.001) is that step's nearest masked tap itself: its next value is
+// v / (1 + 1e-6), whatever its neighbours hold.  So every value written here is carried on through the later steps for as long
+// as it stays above 0.001 (out_n1, out_n2: the outputs of the next two steps, or null), and a DERIVED launch only works on the
+// pixels that did not pass (a tile without one ends after reading its own pixels).
 template <bool DERIVED>
 __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, const float *__restrict__ mask, int H,
-                                              int W, float *__restrict__ out) {
+                                              int W, float *__restrict__ out, float *__restrict__ out_n1,
+                                              float *__restrict__ out_n2) {
     constexpr int half = 3, PW = GM_TW + 6, PH = GM_TH + 6;
+    if (DERIVED) {
+        // the tile's own pixels first: nothing to do unless one of them failed the mask
+        bool hard = false;
+        for (int k = threadIdx.x; k < GM_TH * GM_TW; k += 256) {
+            const int gi = blockIdx.y * GM_TH + k / GM_TW, gj = blockIdx.x * GM_TW + k % GM_TW;
+            if (gi < H && gj < W) hard |= !(data[(size_t)blockIdx.z * H * W + (size_t)gi * W + gj] > 0.001f);
+        }
+        if (!__syncthreads_or(hard)) return;
+    }
     __shared__ float s_d[PH * PW];
     __shared__ float s_m[DERIVED ? 1 : PH * PW];
     const int b = blockIdx.z, r0 = blockIdx.y * GM_TH, c0 = blockIdx.x * GM_TW;
@@ -26,48 +41,97 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ u32 s_mb[PH][4];  // bit c of a row: the mask of padded column c is not zero
     bool odd = false;            // a mask value that is neither 0 nor 1 (only a caller's mask can hold one)
-    for (int r = wave; r < PH; r += 4) {
-        const int gi = r0 + r - half;
+    {
+        // every load of the thread first (independent: one round trip), then the tile and the mask bits
+        constexpr int NR = (PH + 3) / 4;
+        float lv[NR][2], lm[NR][2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c = lane + 64 * k;
-            const int gj = c0 + c - half;
-            const bool in = c < PW && gi >= 0 && gi < H && gj >= 0 && gj < W;
-            const float v = in ? data[fo + (size_t)gi * W + gj] : 0.0f;
-            const float m = DERIVED ? (v > 0.001f ? 1.0f : 0.0f) : (in ? mask[fo + (size_t)gi * W + gj] : 0.0f);
-            if (c < PW) {
-                s_d[r * PW + c] = v;
-                if (!DERIVED) s_m[r * PW + c] = m;
+        for (int q = 0; q < NR; ++q) {
+            const int r = wave + 4 * q, gi = r0 + r - half;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = lane + 64 * k, gj = c0 + c - half;
+                const bool in = r < PH && c < PW && gi >= 0 && gi < H && gj >= 0 && gj < W;
+                const size_t at = in ? fo + (size_t)gi * W + gj : fo;
+                lv[q][k] = data[at];  // (unconditional: a clamped address, the value is dropped below)
+                lm[q][k] = DERIVED ? 0.0f : mask[at];
+                if (!in) lv[q][k] = lm[q][k] = 0.0f;
             }
-            odd |= !(m == 0.0f || m == 1.0f);
-            const u64 bal = __ballot(m != 0.0f);
-            if (lane == 0) {
-                if (k == 0) {
-                    s_mb[r][0] = (u32)bal;
-                    s_mb[r][1] = (u32)(bal >> 32);
-                } else {
-                    s_mb[r][2] = (u32)bal;
-                    s_mb[r][3] = 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int r = wave + 4 * q;
+            if (r >= PH) break;  // wave-uniform
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = lane + 64 * k;
+                const float v = lv[q][k];
+                const float m = DERIVED ? (v > 0.001f ? 1.0f : 0.0f) : lm[q][k];
+                if (c < PW) {
+                    s_d[r * PW + c] = v;
+                    if (!DERIVED) s_m[r * PW + c] = m;
+                }
+                odd |= !(m == 0.0f || m == 1.0f);
+                const u64 bal = __ballot(m != 0.0f);
+                if (lane == 0) {
+                    if (k == 0) {
+                        s_mb[r][0] = (u32)bal;
+                        s_mb[r][1] = (u32)(bal >> 32);
+                    } else {
+                        s_mb[r][2] = (u32)bal;
+                        s_mb[r][3] = 0u;
+                    }
                 }
             }
         }
     }
     const bool binary = !__syncthreads_or(odd);  // block-uniform; the tiles are staged
+    // With a 0 / 1 mask: the L1 distance of every pixel's nearest masked tap, 64 pixels of a row at a time.  E_k of a padded row:
+    // bit c = a masked tap within k columns of pixel c; "nearest tap within t" of an output row = the OR over its seven rows of
+    // E_(t - |di|); seven cumulative words per row, kept as the three bit planes of n = 7 - distance (0: no masked tap).
+    __shared__ u64 s_E[PH][4], s_N[GM_TH][3];
+    if (binary) {
+        if (threadIdx.x < PH) {
+            const int rr = threadIdx.x;
+            const u64 lo = (u64)s_mb[rr][0] | (u64)s_mb[rr][1] << 32, hi = (u64)s_mb[rr][2];
+            auto S = [&](int x) { return lo >> x | hi << (64 - x); };  // the mask bits of padded columns c + x
+            const u64 e0 = S(3), e1 = e0 | S(2) | S(4), e2 = e1 | S(1) | S(5), e3 = e2 | lo | S(6);
+            s_E[rr][0] = e0; s_E[rr][1] = e1; s_E[rr][2] = e2; s_E[rr][3] = e3;
+        }
+        __syncthreads();
+        if (threadIdx.x < GM_TH) {
+            const int r = threadIdx.x;  // output row r: padded rows r .. r + 6, centre r + 3
+            auto E = [&](int k, int d) { return d ? s_E[r + 3 - d][k] | s_E[r + 3 + d][k] : s_E[r + 3][k]; };
+            const u64 t0 = E(0, 0), t1 = E(1, 0) | E(0, 1), t2 = E(2, 0) | E(1, 1) | E(0, 2), t3 = E(3, 0) | E(2, 1) | E(1, 2) | E(0, 3),
+                      t4 = E(3, 0) | E(3, 1) | E(2, 2) | E(1, 3), t5 = E(3, 0) | E(3, 1) | E(3, 2) | E(2, 3),
+                      t6 = E(3, 0) | E(3, 1) | E(3, 2) | E(3, 3);
+            s_N[r][2] = t3;
+            s_N[r][1] = (t5 & ~t3) | t1;
+            s_N[r][0] = (t6 & ~t5) | (t4 & ~t3) | (t2 & ~t1) | t0;
+        }
+        __syncthreads();
+    }
+    auto emit = [&](int r, int c, float acc, float cnt) {
+        const size_t at = fo + (size_t)(r0 + r) * W + c0 + c;
+        float v = __fdiv_rn(acc, __fadd_rn(0.000001f, cnt));
+        out[at] = v;
+        if (out_n1 && v > 0.001f) {
+            v = __fdiv_rn(v, __fadd_rn(0.000001f, 1.0f));
+            out_n1[at] = v;
+            if (out_n2 && v > 0.001f) out_n2[at] = __fdiv_rn(v, __fadd_rn(0.000001f, 1.0f));
+        }
+    };
     // With a 0 / 1 mask the selected taps are the masked taps at the smallest L1 distance from the pixel (w = 7 - |di| - |dj|):
     // that distance from the rows' mask bits (nearest set bit left / right of the centre per row), then at most two taps per
     // row, added to +0 in row-major order as the reference's reduce_sum over the 49 products does (a lone -0.0 comes out as
     // +0.0).  No masked tap in the window: every tap ties at s = 0, all 49 are added.
     auto ring = [&](int r, int c) {
         u32 mbits[7];
-        u32 tmin = 64u;
         const int w = c >> 5;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const u32 mb = __builtin_amdgcn_alignbit(s_mb[r + i][w + 1], s_mb[r + i][w], (u32)c) & 0x7Fu;  // taps j = 0..6: bits 0..6
-            mbits[i] = mb;
-            const u32 hx = min(min(ffbh_u32((mb & 0xFu) << 28), ffbl_b32(mb >> 3)), 64u);
-            tmin = min(tmin, hx + (u32)(i < 3 ? 3 - i : i - 3));
-        }
+        for (int i = 0; i < 7; ++i) mbits[i] = __builtin_amdgcn_alignbit(s_mb[r + i][w + 1], s_mb[r + i][w], (u32)c) & 0x7Fu;  // taps j = 0..6: bits 0..6
+        const u32 n = (u32)((s_N[r][0] >> c) & 1ull) | (u32)((s_N[r][1] >> c) & 1ull) << 1 | (u32)((s_N[r][2] >> c) & 1ull) << 2;
+        const u32 tmin = n ? 7u - n : 64u;
         float acc = 0.0f, cnt = 0.0f;
         if (tmin >= 64u) {
 #pragma unroll
@@ -92,7 +156,7 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
                 }
             }
         }
-        out[fo + (size_t)(r0 + r) * W + c0 + c] = __fdiv_rn(acc, __fadd_rn(0.000001f, cnt));
+        emit(r, c, acc, cnt);
     };
     auto full = [&](int r, int c) {
         float mx = 0.0f, acc = 0.0f, cnt = 0.0f;
@@ -110,7 +174,7 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
                 mx = gt ? sv : mx;
             }
         }
-        out[fo + (size_t)(r0 + r) * W + c0 + c] = __fdiv_rn(acc, __fadd_rn(0.000001f, cnt));
+        emit(r, c, acc, cnt);
     };
     if (!DERIVED) {
         for (int r = wave; r < GM_TH; r += 4)
@@ -129,8 +193,7 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
     for (int r = wave; r < GM_TH; r += 4) {
         const bool in = r0 + r < H && c0 + lane < W;
         const float vc = s_d[(r + 3) * PW + lane + 3];
-        const bool easy = in && vc > 0.001f;
-        if (easy) out[fo + (size_t)(r0 + r) * W + c0 + lane] = __fdiv_rn(vc, __fadd_rn(0.000001f, 1.0f));
+        const bool easy = in && vc > 0.001f;  // (its value went out with the previous step's)
         const u64 bal = __ballot(in && !easy);
         int base = 0;
         if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));

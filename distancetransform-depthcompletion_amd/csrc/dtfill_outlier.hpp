@@ -29,12 +29,25 @@ __global__ __launch_bounds__(256) void k_outlier(const float *__restrict__ x, in
     if (threadIdx.x == 0) s_n = s_neg = 0;
     __syncthreads();
     bool neg = false;
-    for (int k = threadIdx.x; k < (O_TH + 6) * (O_TW + 6); k += 256) {
-        const int r = k / (O_TW + 6), c = k - r * (O_TW + 6);
-        const int gi = reflect101(min(r0 + r - 3, H + 2), H), gj = reflect101(min(c0 + c - 3, W + 2), W);
-        const float v = xf[(size_t)gi * W + gj];
-        neg |= v < 0.0f;
-        s_t[k] = v;
+    {
+        // every load of the thread first (independent: one round trip instead of seven), then the tile
+        constexpr int NIT = (O_TH + 6) * (O_TW + 6), PER = (NIT + 255) / 256;
+        float lv[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int k = min((int)threadIdx.x + 256 * q, NIT - 1);
+            const int r = k / (O_TW + 6), c = k - r * (O_TW + 6);
+            const int gi = reflect101(min(r0 + r - 3, H + 2), H), gj = reflect101(min(c0 + c - 3, W + 2), W);
+            lv[q] = xf[(size_t)gi * W + gj];
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int k = (int)threadIdx.x + 256 * q;
+            if (k < NIT) {
+                neg |= lv[q] < 0.0f;
+                s_t[k] = lv[q];
+            }
+        }
     }
     if (__any(neg) && (threadIdx.x & 63) == 0) s_neg = 1;
     __syncthreads();

@@ -763,6 +763,22 @@ def test_generate_multi_channel_vs_oracle(pkg, oracle):
         got, want = pkg.generate_multi_channel(xx, m, 7, 4), oracle.generate_multi_channel(xx, m, 7, 4)
         for g, w in zip(got, want):
             assert np.array_equal(g, w) and np.array_equal(np.signbit(g), np.signbit(w))
+    # values around the next step's mask threshold (a step carries a pixel's value on through the later steps only while it
+    # stays above 0.001; the pixel right at the edge drops out one step later), tiny and huge values, a NaN
+    x = np.where(rng.random((2, 50, 140, 1)) < 0.06, rng.uniform(0.00099, 0.00101, (2, 50, 140, 1)), 0).astype(np.float32)
+    x[0, 10, 10, 0] = np.float32(0.001) * np.float32(1.000001)
+    x[0, 20, 100, 0] = np.float32(0.001) * np.float32(1.000002)
+    x[1, 5, 5, 0] = 1e-30
+    x[1, 30, 60, 0] = 3e38
+    x[1, 40, 20, 0] = np.nan
+    for m in ((x > 0).astype(np.float32), np.isfinite(x).astype(np.float32) * (x != 0)):
+        got, want = pkg.generate_multi_channel(x, m.astype(np.float32), 7, 4), oracle.generate_multi_channel(x, m.astype(np.float32), 7, 4)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w, equal_nan=True) and np.array_equal(np.signbit(g), np.signbit(w))
+    for sn in (2, 3):
+        got, want = pkg.generate_multi_channel(x, (x > 0).astype(np.float32), 7, sn), oracle.generate_multi_channel(x, (x > 0).astype(np.float32), 7, sn)
+        for g, w in zip(got, want):
+            assert (g is None) == (w is None) and (g is None or np.array_equal(g, w, equal_nan=True))
 
 
 def test_shape_errors(gpu_op, pkg):
