@@ -138,17 +138,17 @@ def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, w
     # each kernel x the pixels dtfill_pass_stats says it owned), not with the whole batch
     win = max((k for k in live if k.startswith("k_l2win")), key=lambda k: live[k], default=None)
     # (the tiles of the frames with a handful of sources -- k_pts, 12 B/px: they read a source list, not the frame -- ride in
-    # k_fused's launch)
-    per_px = {"k_mask": (4.3, px["all"]), "k_frame": (0.0, 0), "k_fused": (16.0, px["window"] + 0.75 * px["points"]),
-              "k_colT": (1.0, 0.38 * px["colt"] + 12.0 * px["sky"]),  # (k_sky's blocks ride in k_colT's launch: 12 B per sky pixel)
-              "k_rows": (8.85, px["anydist"]), "k_fin": (20.6, px["anydist"]), "k_tiesx": (0.0, 0),
-              "k_l2far": (0.0, 0), "k_l2env": (20.25, px["anydist"] + px["points"])}
+    # k_fin's launch)
+    per_px = {"k_mask": [(4.3, px["all"])], "k_frame": [], "k_fused": [(16.0, px["window"])],
+              "k_colT": [(0.38, px["colt"]), (12.0, px["sky"])],  # (k_sky's blocks ride in k_colT's launch: 12 B per sky pixel)
+              "k_rows": [(8.85, px["anydist"])], "k_fin": [(20.6, px["anydist"]), (12.0, px["points"])], "k_tiesx": [],
+              "k_l2far": [], "k_l2env": [(20.25, px["anydist"] + px["points"])]}
     if win:
-        per_px[win] = (16.13, px["window"])
+        per_px[win] = [(16.13, px["window"])]
     kern = {}
     for k, ms in live.items():
-        bpp, n = per_px.get(k, (0.0, 0))
-        nbytes = bpp * n
+        parts = per_px.get(k, [])
+        nbytes, n = sum(bpp * m for bpp, m in parts), sum(m for _, m in parts)
         kern[k] = {"ms": round(ms, 4), "algorithmic_bytes": int(nbytes), "pixels": int(n),
                    "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     dom = max(live, key=live.get)

@@ -29,8 +29,6 @@
 //              level-synchronous form of the identity on bit planes held in registers, byte codes un-sliced into LDS,
 //              lock-step chain walk, rank lookup, depth gather and the three output stores.  Hands a ROW on when one of its
 //              pixels is farther than the halo from every source.
-//              + the tiles of the frames with a handful of sources ("k_pts", dtfill_pts.hpp) in the same launch: candidates
-//              per wave box, dominance pruning, packed-key minima per pixel, k_fin's rule for the tie pixels
 //   every other frame, and the handed-on rows (any distance, any density; dtfill_rows.hpp):
 //   k_colT     per 32-row band and column: the band's source bits and the distances to the nearest source
 //              above / below the band -- everything a row needs to know about its columns; and the label of
@@ -41,6 +39,9 @@
 //              a pixel with ONE nearest source needs no chain), live; distance map + bit planes
 //   k_fin      per tile: 5x5 parent rule bit-sliced for the remaining "tie" pixels, their chains (up to four hops through
 //              the step bytes in LDS), label + depth of every pixel
+//              + the tiles of the frames with a handful of sources ("k_pts", dtfill_pts.hpp) in the same launch: candidates
+//              per wave box, dominance pruning, packed-key minima per pixel by one sweep down and one up, the same rule for
+//              their tie pixels -- from the source list to the three outputs
 //   k_tiesx    the few tie pixels whose chain crosses tiles or runs longer: follows the recorded links
 // l2 pass (exact Euclidean, canonical tie-break; dtfill_l2.hpp): k_mask, k_frame, then
 //   k_l2win<R> dense frames: (2R+1)^2 windows straight from the bit words, packed-key minimum over the window rows

@@ -125,7 +125,17 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
     // that distance from the rows' mask bits (nearest set bit left / right of the centre per row), then at most two taps per
     // row, added to +0 in row-major order as the reference's reduce_sum over the 49 products does (a lone -0.0 comes out as
     // +0.0).  No masked tap in the window: every tap ties at s = 0, all 49 are added.
-    auto ring = [&](int r, int c) {
+    auto none49 = [&](int r, int c) {  // no masked tap in the window: every tap ties at s = 0
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc = __fadd_rn(acc, s_d[(r + i) * PW + c + j]);
+        emit(r, c, acc, 49.0f);
+    };
+    // INLINE49: the "no masked tap" pixels are evaluated here; otherwise the caller has listed them (returns true for such a pixel)
+    auto ring = [&](int r, int c, auto inline49) -> bool {
+        constexpr bool INLINE49 = decltype(inline49)::value;
         u32 mbits[7];
         const int w = c >> 5;
 #pragma unroll
@@ -134,12 +144,10 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
         const u32 tmin = n ? 7u - n : 64u;
         float acc = 0.0f, cnt = 0.0f;
         if (tmin >= 64u) {
-#pragma unroll
-            for (int i = 0; i < 7; ++i)
-#pragma unroll
-                for (int j = 0; j < 7; ++j) acc = __fadd_rn(acc, s_d[(r + i) * PW + c + j]);
-            cnt = 49.0f;
-        } else {
+            if (INLINE49) none49(r, c);
+            return true;
+        }
+        {
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
                 const int dx = (int)tmin - (i < 3 ? 3 - i : i - 3);
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
             }
         }
         emit(r, c, acc, cnt);
+        return false;
     };
     auto full = [&](int r, int c) {
         float mx = 0.0f, acc = 0.0f, cnt = 0.0f;
@@ -176,20 +185,35 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
         }
         emit(r, c, acc, cnt);
     };
-    if (!DERIVED) {
-        for (int r = wave; r < GM_TH; r += 4)
-            if (r0 + r < H && c0 + lane < W) {
-                if (binary)
-                    ring(r, lane);
-                else
-                    full(r, lane);
-            }
-        return;
-    }
     __shared__ u16 s_list[GM_TH * GM_TW];
     __shared__ int s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
+    if (!DERIVED) {
+        if (!binary) {
+            for (int r = wave; r < GM_TH; r += 4)
+                if (r0 + r < H && c0 + lane < W) full(r, lane);
+            return;
+        }
+        // the pixels without a masked tap in their window (8 % at 5 % density: nearly every wave holds one) are listed and
+        // summed afterwards, 64 of them per wave, instead of every wave walking through the 49 taps for its one or two
+        for (int r = wave; r < GM_TH; r += 4) {
+            const bool in = r0 + r < H && c0 + lane < W;
+            const bool none = in && ring(r, lane, std::false_type{});
+            const u64 bal = __ballot(none);
+            int base = 0;
+            if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (none) s_list[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (u16)(r * GM_TW + lane);
+        }
+        __syncthreads();
+        const int n49 = s_n;
+        for (int t = threadIdx.x; t < n49; t += 256) {
+            const int k = s_list[t];
+            none49(k / GM_TW, k % GM_TW);
+        }
+        return;
+    }
     for (int r = wave; r < GM_TH; r += 4) {
         const bool in = r0 + r < H && c0 + lane < W;
         const float vc = s_d[(r + 3) * PW + lane + 3];
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
     const int n = s_n;
     for (int t = threadIdx.x; t < n; t += 256) {
         const int k = s_list[t];
-        ring(k / GM_TW, k % GM_TW);
+        ring(k / GM_TW, k % GM_TW, std::true_type{});
     }
 }
 

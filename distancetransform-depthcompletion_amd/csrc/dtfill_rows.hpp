@@ -17,7 +17,8 @@
 //
 // Which rows: all of a frame k_frame routes here (fflag 2), or the rows flagged 1 of a window-kernel frame (fflag 1: rows
 // too far from every source row, marked by k_frame up front; rows in which k_fused met a pixel beyond its halo; the sky's
-// rows when k_fused had to call k_sky off).  A frame of k_pts (fflag 3) only passes through k_tiesx.
+// rows when k_fused had to call k_sky off).  A frame of k_pts (fflag 3) has its tiles in k_fin's launch (dtfill_pts.hpp) and
+// passes through k_tiesx.
 //
 //   k_colT   srcbits -> per 32-row band and column: the band's source bits of that column (one word) and
 //            the distance from the band's first / last row to the nearest source above / below the band:
