@@ -47,26 +47,26 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
         float lv[NR][2], lm[NR][2];
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
-            const int r = wave + 4 * q, gi = r0 + r - half;
+            // (clamped addresses, unconditional loads: what lies outside the image is dropped below)
+            const int gi = min(max(r0 + wave + 4 * q - half, 0), H - 1);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int c = lane + 64 * k, gj = c0 + c - half;
-                const bool in = r < PH && c < PW && gi >= 0 && gi < H && gj >= 0 && gj < W;
-                const size_t at = in ? fo + (size_t)gi * W + gj : fo;
-                lv[q][k] = data[at];  // (unconditional: a clamped address, the value is dropped below)
-                lm[q][k] = DERIVED ? 0.0f : mask[at];
-                if (!in) lv[q][k] = lm[q][k] = 0.0f;
+                const int gj = min(max(c0 + lane + 64 * k - half, 0), W - 1);
+                const u32 at = (u32)gi * (u32)W + (u32)gj;
+                lv[q][k] = data[fo + at];
+                lm[q][k] = DERIVED ? 0.0f : mask[fo + at];
             }
         }
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
-            const int r = wave + 4 * q;
+            const int r = wave + 4 * q, gi = r0 + r - half;
             if (r >= PH) break;  // wave-uniform
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int c = lane + 64 * k;
-                const float v = lv[q][k];
-                const float m = DERIVED ? (v > 0.001f ? 1.0f : 0.0f) : lm[q][k];
+                const int c = lane + 64 * k, gj = c0 + c - half;
+                const bool in = gi >= 0 && gi < H && gj >= 0 && gj < W;
+                const float v = in ? lv[q][k] : 0.0f;
+                const float m = DERIVED ? (v > 0.001f ? 1.0f : 0.0f) : (in ? lm[q][k] : 0.0f);
                 if (c < PW) {
                     s_d[r * PW + c] = v;
                     if (!DERIVED) s_m[r * PW + c] = m;

@@ -542,6 +542,11 @@ def test_l1_frames_with_a_handful_of_sources(gpu_op, oracle):
         assert_equal_to_oracle(oracle, gpu_op, pts(H, W, min(3, H * W))[None])
     for (H, W, n) in [(200, 300, 40), (480, 600, 150), (130, 129, 12), (65, 640, 30)]:  # shapes that take the 64 x 128 tiles, ragged either way
         assert_equal_to_oracle(oracle, gpu_op, np.stack([pts(H, W, n), pts(H, W, 2 * n)]))
+    # the widest frame whose keys still hold distance and column (H + W <= 8100): sources all over, and one in a corner
+    assert_equal_to_oracle(oracle, gpu_op, pts(30, 8060, 120)[None], paths=("auto",))
+    x = np.zeros((1, 40, 8060), np.float32)
+    x[0, 39, 8059] = 2.0
+    assert_equal_to_oracle(oracle, gpu_op, x, paths=("auto",))
     x = np.stack([pts(128, 640, 60), pts(128, 640, 30)])
     x[0, 5, :40] = 0.5                    # values that are not sources: misaligned enumerations
     assert_equal_to_oracle(oracle, gpu_op, x)
