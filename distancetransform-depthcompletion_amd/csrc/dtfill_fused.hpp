@@ -38,7 +38,8 @@ constexpr int F_EB = 8;                // tile pixels per lane walked in lock-st
 // byte code of a decided pixel: 2 * enc (a source: 2 * 18 = step (0,0))
 constexpr int F_NONE = 2 * 63;         // byte code of an undecided pixel: table entry 63, also step (0,0)
 static_assert(F_WWM == 32 * F_NWD, "window width must be six words");
-static_assert(F_RING * 4 >= F_WHM * F_P, "s_par must fit in the ring's memory");
+static_assert(F_RING * 4 >= F_WHM * F_P + 256 * 8, "s_par and the un-slicing table must fit in the ring's memory");
+static_assert((F_WHM * F_P) % 8 == 0 && F_WHM * F_P >= 4 * (1 + 4 * F_RPLANE), "the table is 8-byte aligned and lies behind the planes of P1b");
 
 #define ENC_F(t) (((TAP_DI(t) + 2) << 3) | (TAP_DJ(t) + 2))
 
@@ -480,6 +481,10 @@ __device__ __forceinline__ void fused_body(bool premarked,
     // ---- P1b: the backward taps of ALL levels in one pass (pixels that are decided but not live).  The d mod 8
     // planes and D go through the ring's memory (slots 0 and 1; its guard rows and pad words are still zero).
     __syncthreads();  // every wave is out of the level loop: the ring is dead
+    // (for P2, in the ring's tail that neither the planes below nor s_par use: a byte of a bit plane -> its eight bits in the
+    // low bits of eight bytes)
+    uint2 *s_lut = reinterpret_cast<uint2 *>(reinterpret_cast<u8 *>(s_ring) + F_WHM * F_P);
+    s_lut[tid] = make_uint2((((u32)tid & 15u) * 0x00204081u) & 0x01010101u, (((u32)tid >> 4) * 0x00204081u) & 0x01010101u);
     ring_store3(s_ring, 0, 0, r + 2, wb, P0);
     ring_store3(s_ring, 0, 1, r + 2, wb, P1);
     ring_store3(s_ring, 1, 0, r + 2, wb, P2);
@@ -513,27 +518,29 @@ __device__ __forceinline__ void fused_body(bool premarked,
         bwd_tap<1, 1, 36 - ENC_F(7)>(a0, a1, a2, dv, P0, P1, P2, taken, C);
     }
 
-    // ---- P2: un-slice the code planes of this half row into bytes, 4 pixels per step.
-    // ((nibble * 0x00204081) & 0x01010101) spreads bits 0..3 of the nibble to the low bits of 4 bytes
-    // (a 24-bit multiply: full rate, v_mul_lo_u32 is quarter rate).
+    // ---- P2: un-slice the code planes of this half row into bytes (2 * enc), 8 pixels per step: a byte of a plane goes
+    // through the table above (one 8-byte LDS read), two shift-ors put it into its bit of the eight bytes.  Undecided pixels
+    // (not in D) get every plane bit: 2 * 63 = F_NONE.
     u8 *s_par = reinterpret_cast<u8 *>(s_ring);
     __syncthreads();  // the ring is dead for everybody before its memory becomes s_par
     {
         u32 *prow = reinterpret_cast<u32 *>(s_par + r * F_P) + wb * 8;
 #pragma unroll
         for (int i = 0; i < F_HW; ++i) {
+            u32 cj[6];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                u32 v = 0;
+            for (int j = 0; j < 6; ++j) cj[j] = C[j][i] | ~D[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u32 lo = 0, hi = 0;
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const u32 nib = (C[j][i] >> (4 * q)) & 0xFu;
-                    v |= (mul_u24_opaque(nib, 0x00204081u) & 0x01010101u) << (j + 1);  // byte = 2 * enc
+                    const uint2 sp = s_lut[(cj[j] >> (8 * q)) & 0xFFu];
+                    lo |= sp.x << (j + 1);
+                    hi |= sp.y << (j + 1);
                 }
-                // undecided pixels (not in D): no plane bit is set; give them F_NONE
-                const u32 und = mul_u24_opaque((~D[i] >> (4 * q)) & 0xFu, 0x00204081u) & 0x01010101u;
-                // (und has bit 24 set for the nibble's 4th pixel: NOT a 24-bit multiply)
-                prow[i * 8 + q] = v | und * (u32)F_NONE;
+                prow[i * 8 + 2 * q] = lo;
+                prow[i * 8 + 2 * q + 1] = hi;
             }
         }
     }
