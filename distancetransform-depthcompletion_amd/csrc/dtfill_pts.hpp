@@ -275,33 +275,39 @@ __device__ __forceinline__ void pts_body(unsigned char *__restrict__ s_raw, cons
                     for (int c = nA; c < nB; ++c) body(c, std::integral_constant<int, 1>{});
                     for (int c = nB; c < nw; ++c) body(c, std::integral_constant<int, 2>{});
                 }
+                // the chunk's rows in three passes over the registers, so that the lookups of all rows are in flight together:
+                // plane bits; the winners' list indices and depths (ds_bpermute from the lanes that hold the candidates); stores
+                constexpr int DS = FAST ? 19 : 15;  // the distance's place in the keys
+                u32 cb[P_RC];                       // d mod 8 | live << 3 | tie << 4 | in-image << 5, at bit 9 (all zero outside the image)
 #pragma unroll
                 for (int u = 0; u < P_RC; ++u) {
-                    const int row = rb + u, i = ib + u;  // wave-uniform
-                    const bool rin = (unsigned)i < (unsigned)H;
-                    const u32 k1 = K1[u], k3 = K3[u];
-                    constexpr int DS = FAST ? 19 : 15;  // the distance's place in the keys
-                    const u32 d = k1 >> DS;
+                    const u32 k1 = K1[u], k3 = K3[u], d = k1 >> DS;
                     // (a source pixel, d = 0, is no tie pixel: no second source shares its pixel, M2's distance is larger)
                     const bool tie = (M2[u] >> DS) == d;
                     const u32 col3 = FAST ? (k3 >> 6) & 8191u : k3 & 8191u;
                     const bool live = ((k3 >> (FAST ? 19 : 13)) == d) & (3 * (int)col3 <= (int)(2u * d) + j3);
-                    // the winner's list index: in the key, or with the candidate in lane k1 & 63
-                    const u32 i1 = FAST ? (u32)__shfl((int)myidx, (int)(k1 & 63u)) : (k1 >> 6) & 511u;
-                    // the pixel's plane bits ride with its index: d mod 8 | live << 3 | tie << 4 | in-image << 5 (all zero outside)
-                    u32 sv = 0u;
-                    if (rin) sv = jin ? (i1 | ((d & 7u) | (live ? 8u : 0u) | (tie ? 16u : 0u) | 32u) << 9) : 0u;
-                    s_src[32 * wr + row][2 + 64 * wcol + lane] = (u16)sv;
-                    if (rin && row >= 2 && row < 34) {  // the wave's own 32 rows
+                    const bool rin = (unsigned)(ib + u) < (unsigned)H;  // wave-uniform
+                    cb[u] = (rin && jin) ? ((d & 7u) | (live ? 8u : 0u) | (tie ? 16u : 0u) | 32u) << 9 : 0u;
+                }
+                u32 i1[P_RC];   // the winner's list index: in the key, or with the candidate in lane k1 & 63
+                float val[P_RC];
+#pragma unroll
+                for (int u = 0; u < P_RC; ++u) {
+                    i1[u] = FAST ? (u32)__shfl((int)myidx, (int)(K1[u] & 63u)) : (K1[u] >> 6) & 511u;
+                    val[u] = depth_now ? __shfl(myval, (int)(K1[u] & 63u)) : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < P_RC; ++u) {
+                    const int row = rb + u, i = ib + u;  // wave-uniform
+                    // the pixel's plane bits ride with its index
+                    s_src[32 * wr + row][2 + 64 * wcol + lane] = (u16)(cb[u] ? (i1[u] | cb[u]) : 0u);
+                    if ((unsigned)i < (unsigned)H && row >= 2 && row < 34 && jin) {  // the wave's own 32 rows
                         // the tile's own pixels: the distance now; label and depth too unless a chain has to be followed (phase 4)
-                        const float val = depth_now ? __shfl(myval, (int)(k1 & 63u)) : 0.0f;
-                        if (jin) {
-                            const u32 ob = (u32)(__umul24((u32)i, (u32)W) + (u32)j) << 2;
-                            if (dt_f) st_off_nt(dt_f, ob, (float)d);
-                            if (!tie) {
-                                if (ix_f) st_off_nt(ix_f, ob, (int32_t)i1 + 1);
-                                if (depth_now) st_off_nt(dp_f, ob, val);
-                            }
+                        const u32 ob = (u32)(__umul24((u32)i, (u32)W) + (u32)j) << 2;
+                        if (dt_f) st_off_nt(dt_f, ob, (float)(K1[u] >> DS));
+                        if (!((cb[u] >> 13) & 1u)) {
+                            if (ix_f) st_off_nt(ix_f, ob, (int32_t)i1[u] + 1);
+                            if (depth_now) st_off_nt(dp_f, ob, val[u]);
                         }
                     }
                 }
