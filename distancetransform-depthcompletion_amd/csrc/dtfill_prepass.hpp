@@ -426,9 +426,9 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         PtsSrc *list = ptslist + (size_t)b * L2_PTS_MAX;
         const float *xf = x + (size_t)b * H * W;
         // an item = one 64-pixel word of a row that holds a source (the rows were listed above); a word's sources go to their
-        // raster ranks.  Four items per step, and everything an item needs before its depths is loaded at once (this block alone
+        // raster ranks.  Eight items per step, and everything an item needs before its depths is loaded at once (this block alone
         // works on the frame: the chain of dependent loads is what the step costs)
-        constexpr int NQ = 4;
+        constexpr int NQ = 8;
         const int nitems = min(s_nrow, L2_PTS_MAX) * Wd;
         for (int it0 = tid; it0 < nitems; it0 += 256 * NQ) {
             u64 sb[NQ];
