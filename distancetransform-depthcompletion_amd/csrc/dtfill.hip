@@ -208,6 +208,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
             // columns in whole 128-byte lines when the window allows it: the runs of a tile row a wave stores are then whole lines
             if (((t.TW + 31) & ~31) <= TWM) t.TW = (t.TW + 31) & ~31;
             t.tiles_x = ntx;
+            t.nty = nty;
             t.ntiles = ntx * nty;
             return t;
         };
@@ -222,7 +223,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
     if (rowflags && !out_dt) out_dt = c.dscratch;
     k_frame<<<B, 256, 0, st>>>(x, c.valbits, c.wpre_v, c.srcbits, c.wpre_s, c.ptslist, c.rowcnt_s, c.rowcnt_v, H, W, Wd, c.rowbase_s, c.rowbase_v,
                                c.finfo, c.vlist, c.fflag2, c.route, status, (general_only ? 1 : 0) | (rowflags ? 4 | 8 : 0), c.negflag, c.rowfar,
-                               t16.TH, t32.TH);
+                               t16.nty, t32.nty);
     mark();
     if (!general_only) {
         // dense frames: the window kernel, halo 16 or 32 per frame (k_frame's route).  It hands rows on (fflag2, rowflag) when a

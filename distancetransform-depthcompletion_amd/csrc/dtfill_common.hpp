@@ -12,6 +12,8 @@ constexpr int FI_NUNRES = 4;  // tie pixels k_fin handed to k_tiesx (zeroed by k
 constexpr int FI_SKY = 5;     // l1_cv: rows [0, FI_SKY) hold no source and lie above every source: k_sky's (0: none, or called off)
 constexpr int FI_SKY0 = 6;    // ... as k_frame set it.  k_fused calls the sky off (FI_SKY = 0) when it has to hand on one of the two rows
                               // k_sky would start from (FI_SKY0, FI_SKY0 + 1): the sky's rows then count as flagged 1
+constexpr int FI_TR0 = 7;     // l1_cv, a window kernel's frame: the first row of its tiling (the rows above are the sky's: the tile rows split
+                              // the rest evenly, so that no tile row is spent on rows that are not the window's)
 constexpr int FI_STRIDE = 8;
 constexpr int ROUTE_POINTS = -1;  // route[b]: l2, at most L2_PTS_MAX sources in the frame (k_l2pts)
 constexpr int L2_PTS_MAX = 512;

@@ -282,24 +282,28 @@ __device__ __forceinline__ bool fused_walk_epilogue(
 // FR = halo = largest distance the window can decide.
 // Geometry of one halo's tiling (host side computes it; the window is always F_WHM x F_WWM)
 struct FusedTiles {
-    int TH, TW, tiles_x, ntiles;
+    int TH, TW, tiles_x, ntiles, nty;  // TH: the tile rows' height when they split the whole frame (the largest it gets)
 };
 
 template <int FR, bool EPI, bool STREAM>
 __device__ __forceinline__ void fused_body(bool premarked,
     const float *__restrict__ x, const u64 *__restrict__ srcbits, const u16 *__restrict__ wpre_s,
     const u32 *__restrict__ rowbase_s, int *__restrict__ finfo, const float *__restrict__ vlist,
-    int H, int W, int Wd, int TH, int TW, int tiles_x, float *__restrict__ out_depth,
+    int H, int W, int Wd, int nty, int TW, int tiles_x, float *__restrict__ out_depth,
     float *__restrict__ out_dt, int32_t *__restrict__ out_index,
     int *__restrict__ fflag, int *__restrict__ frame_status, const DepthEpilogue ep, u32 *__restrict__ s_ring, uint2 *__restrict__ s_rw,
     short *__restrict__ s_tab, u32 (*__restrict__ s_any)[F_NT / 64]) {
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    int r0 = ty * TH;
+    // the tile rows split the rows from FI_TR0 on evenly (k_frame: 0, or the first source row under a sky)
+    const int tbase = finfo[b * FI_STRIDE + FI_TR0];
+    const int TH = (H - tbase + nty - 1) / nty;
+    int r0 = tbase + ty * TH;
     const int c0 = tx * TW;
     int th = min(TH, H - r0);
     const int tw = min(TW, W - c0);
+    if (th <= 0) return;  // block-uniform
     if (premarked) {
         // k_frame handed rows of this frame to the any-distance kernels up front (the empty sky): the tile shrinks to the span
         // of its rows that are still this kernel's; a tile without any is done.  (A row another block marks meanwhile is
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     const bool pre = rt > 0 && (rt & ROUTE_PREMARK);
     const bool epi = ep.row0 != 0 || ep.use_floor;  // uniform: the plain pass runs code compiled without the epilogue
 #define FUSED_CALL(FR_, EPI_, T_)                                                                                        \
-    fused_body<FR_, EPI_, STREAM && !(EPI_)>(pre, x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, T_.TH, T_.TW, T_.tiles_x, out_depth, out_dt, \
+    fused_body<FR_, EPI_, STREAM && !(EPI_)>(pre, x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, T_.nty, T_.TW, T_.tiles_x, out_depth, out_dt, \
                           out_index, fflag, frame_status, ep, s_ring, s_rw, s_tab, s_any)
     if (r == 16 && (int)blockIdx.x < t16.ntiles) {
         if (epi)

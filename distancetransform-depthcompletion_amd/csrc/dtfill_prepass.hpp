@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
                                                int *__restrict__ finfo, float *__restrict__ vlist,
                                                int *__restrict__ fflag2,
                                                int *__restrict__ route, int *__restrict__ frame_status, int mode, int *__restrict__ negflag,
-                                               u32 *__restrict__ rowfar, int th16, int th32) {
+                                               u32 *__restrict__ rowfar, int nty16, int nty32) {
     const bool force_general = mode & 1;  // every frame takes the any-distance kernels (tests)
     const bool l2 = mode & 2;             // l2: the window kernel's cost does not grow with the distances it meets
     const bool premark = mode & 4;        // l1_cv without a depth epilogue: rows too far from every source row are handed on up front
@@ -462,16 +462,19 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
     if (flags && r > 0) {
         // a tile row of the window kernel that is left with only a few rows is not worth its windows: all of it goes to the
         // any-distance kernels.  One thread per tile row, whole words at a time.
-        const int TH = r == 16 ? th16 : th32;
+        // the window kernel's tile rows: nty of them over the rows from the first source row on when the rows above are the
+        // sky's, else over the whole frame (fused_body computes the same)
+        const int nty = r == 16 ? nty16 : nty32, tbase = sky_ok ? r0 : 0;
+        const int TH = (H - tbase + nty - 1) / nty;
         auto bits = [&](int a, int e, int w) {  // the rows [a, e) as bits of word w
             const int lo = max(a - 32 * w, 0), hi = min(e - 32 * w, 32);
             return hi <= lo ? 0u : (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
         };
-        for (int t = tid; t * TH < H; t += 256) {
-            const int a = max(t * TH, sky_ok ? r0 : 0), e = min(H, (t + 1) * TH);  // its rows below the sky
+        for (int t = tid; tbase + t * TH < H; t += 256) {
+            const int a = tbase + t * TH, e = min(H, tbase + (t + 1) * TH);  // its rows (all below the sky)
             int keep = 0;
             for (int w = a >> 5; w <= (e - 1) >> 5 && a < e; ++w) keep += __popc(~far[w] & bits(a, e, w));
-            if (keep && 4 * keep <= min(H, (t + 1) * TH) - t * TH)
+            if (keep && 4 * keep <= e - a)
                 for (int w = a >> 5; w <= (e - 1) >> 5; ++w) atomicOr(&far[w], bits(a, e, w));
         }
     }
@@ -496,6 +499,7 @@ __global__ __launch_bounds__(256) void k_frame(const float *__restrict__ x, cons
         finfo[b * FI_STRIDE + FI_DLB] = s_dlb;
         finfo[b * FI_STRIDE + FI_NUNRES] = 0;
         finfo[b * FI_STRIDE + FI_SKY] = finfo[b * FI_STRIDE + FI_SKY0] = (flags && sky) ? r0 : 0;
+        finfo[b * FI_STRIDE + FI_TR0] = (flags && r > 0 && sky_ok) ? r0 : 0;
         const bool marked = flags && r > 0 && (sky || any1);
         route[b] = marked ? (r | ROUTE_PREMARK) : r;
         negflag[b] = 0;  // k_mask_o's "this frame holds a negative value": consumed before this kernel, reset for the next pass
