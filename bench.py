@@ -44,6 +44,7 @@ PKG = "distancetransform-depthcompletion_amd"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_PIXEL = 16   # read f32 depth, write f32 depth + f32 distance + i32 index
 EXTRA_WORKLOADS = ("kitti_b32_scanline", "nyu_b64", "synth2048_b16")
+XSTEPS = 50  # timed passes of the extra workloads (behind a warm-up that runs until their pass time has settled)
 
 
 def host_cores():
@@ -103,8 +104,25 @@ def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, w
     """W untimed passes, then exactly `steps` timed ones between barrier + synchronize; per-kernel HIP-event
     times from a few instrumented passes.  Returns (line fields, roofline dict)."""
     B, H, W = x.shape
-    for _ in range(warmup):
-        op.run(x, path=path)
+    if warmup is None:
+        # no --warmup given: warm up until the pass time has settled (the first few hundred passes after an idle spell run slower:
+        # clocks, and whatever the process before left behind) -- at least 300 passes, then chunks of 100 until two in a row agree
+        # within 1.5 %, at most 3000.  All of it untimed; the count is reported as "warmup".
+        warmup, prev = 0, None
+        while warmup < 3000:
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                op.run(x, path=path)
+            barrier()
+            dt_ = reduce_max(time.perf_counter() - t0)
+            warmup += 100
+            if warmup >= 300 and prev is not None and abs(dt_ - prev) <= 0.015 * prev:
+                break
+            prev = dt_
+    else:
+        for _ in range(warmup):
+            op.run(x, path=path)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -168,7 +186,7 @@ def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, w
         "pass_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "pass_traffic": t.get("pass_bytes") if t.get("batch") == B else None,
     }
-    out = {"ms_per_step": round(ms_per_step, 4), "elapsed": elapsed, "frames_with_index_error": status_bad,
+    out = {"ms_per_step": round(ms_per_step, 4), "elapsed": elapsed, "warmup_done": warmup, "frames_with_index_error": status_bad,
            "frames_on_general_path": general_frames}
     if rep:
         srt = sorted(rep)
@@ -181,9 +199,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: the first few hundred passes after an idle spell run at ramping clocks (96 us per pass with 10 warm-up passes, 90.7
-    # with 300 and ever after); both loops together still take a twentieth of a second
+    # with 300 and ever after; once 125 us behind 300 right after a profiler run): without --warmup the untimed passes go on until
+    # two chunks of 100 agree (measure()); the driver's --warmup W is taken as given
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed passes before the timed ones (default: until the pass time has settled, 300 to 3000)")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default: the workload's)")
     ap.add_argument("--workload", default="kitti_b32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -300,7 +319,7 @@ def main():
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
-            "warmup": args.warmup,
+            "warmup": res["warmup_done"],
             "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
@@ -324,8 +343,8 @@ def main():
             for name in EXTRA_WORKLOADS:
                 c = synth.CONFIGS[name]
                 xw = torch.from_numpy(synth.make(name)).to(dev)
-                r, rf = measure(op, torch, xw, 30, 50, args.path, barrier, reduce_max, workload=name, traffic=traffic)
-                wl[name] = {"value": round(c["B"] * 30 / r["elapsed"], 1), "unit": "frames/s", "frames": c["B"],
+                r, rf = measure(op, torch, xw, XSTEPS, None, args.path, barrier, reduce_max, workload=name, traffic=traffic)
+                wl[name] = {"value": round(c["B"] * XSTEPS / r["elapsed"], 1), "unit": "frames/s", "frames": c["B"],
                             "shape": [c["H"], c["W"]], "ms_per_step": r["ms_per_step"], "roofline": rf,
                             "frames_on_general_path": r["frames_on_general_path"]}
                 del xw
@@ -336,8 +355,8 @@ def main():
             for name in (args.workload,) + tuple(EXTRA_WORKLOADS):
                 c = synth.CONFIGS[name]
                 xw = x if name == args.workload else torch.from_numpy(synth.make(name)).to(dev)
-                r, rf = measure(op2, torch, xw, 30, 50, "auto", barrier, reduce_max, workload=name + "_l2", traffic=traffic)
-                l2[name] = {"value": round(xw.shape[0] * 30 / r["elapsed"], 1), "unit": "frames/s", "frames": int(xw.shape[0]),
+                r, rf = measure(op2, torch, xw, XSTEPS, None, "auto", barrier, reduce_max, workload=name + "_l2", traffic=traffic)
+                l2[name] = {"value": round(xw.shape[0] * XSTEPS / r["elapsed"], 1), "unit": "frames/s", "frames": int(xw.shape[0]),
                             "ms_per_step": r["ms_per_step"], "roofline": rf}
                 del xw
             line["l2"] = l2
