@@ -78,6 +78,14 @@ class HostSlab:
             if rank != 0:
                 for k in self.names:
                     self._shm[k] = shared_memory.SharedMemory(name=box[0][k])
+                    # (Python < 3.13 registers an ATTACHED segment with this process's resource tracker as well, which then tries
+                    # to unlink rank 0's segment at exit and warns that it is gone: only the creator owns it)
+                    try:
+                        from multiprocessing import resource_tracker
+
+                        resource_tracker.unregister(self._shm[k]._name, "shared_memory")
+                    except Exception:
+                        pass
         self.arrays, self.tensors, self._registered = {}, {}, []
         self._handed = []  # weak references to the arrays handed to the caller from this slab
         if pin is None:
