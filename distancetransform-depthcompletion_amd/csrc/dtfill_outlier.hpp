@@ -10,14 +10,14 @@
 // the 25 taps are only gathered for those (a few percent of a LiDAR frame).  A negative value anywhere switches to the
 // exhaustive evaluation: per tile in k_outlier, per frame (a second launch) in k_mask_o.
 // ------------------------------------------------------------------------------------------------
-constexpr int O_TH = 16, O_TW = 64;
+constexpr int O_TH = 16, O_TW = 128;
 
 __device__ __forceinline__ int reflect101(int p, int n) {
     p = p < 0 ? -p : p;
     return p >= n ? 2 * n - 2 - p : p;
 }
 
-// k_outlier: one block per 16 x 64 tile staged in LDS with a 3-cell halo; candidates (v > 1.0, or every pixel when the
+// k_outlier: one block per 16 x 128 tile staged in LDS with a 3-cell halo; candidates (v > 1.0, or every pixel when the
 // staged tile holds a negative value) are compacted so that every lane evaluates one.
 __global__ __launch_bounds__(256) void k_outlier(const float *__restrict__ x, int H, int W,
                                                  float *__restrict__ out) {

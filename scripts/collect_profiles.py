@@ -33,4 +33,7 @@ for f in ("bench_default.json", "bench_l2.json", "bench_outlier.txt", "bench_gmc
         shutil.copy(p, os.path.join(dst, f))
 for f in glob.glob(os.path.join(src, "side_*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+for d in glob.glob(os.path.join(src, "side_*", "")):  # scripts/profile_side.sh: trace + HBM counters of the neighbours' kernels
+    if os.path.exists(os.path.join(d, "summary.txt")):
+        shutil.copy(os.path.join(d, "summary.txt"), os.path.join(dst, os.path.basename(d.rstrip("/")) + "_summary.txt"))
 print("profiles/%s:" % tag, sorted(os.listdir(dst)))

@@ -21,7 +21,7 @@ def rows(pattern):
 
 
 def short(n):
-    m = re.search(r"(k_l2win<\d+>|k_[a-zA-Z0-9_]+)", n)  # k_l2win<10> keeps its radius, k_rows<8, 256> is k_rows
+    m = re.search(r"(k_l2win<\d+>|k_gmc7<\w+>|k_[a-zA-Z0-9_]+)", n)  # k_l2win<10> keeps its radius, k_gmc7<false> its step kind, k_rows<8, 256> is k_rows
     return m.group(1) if m else None
 
 
