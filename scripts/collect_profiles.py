@@ -19,7 +19,7 @@ traffic = {"source": "profiles/%s/<workload>_summary.txt: rocprofv3 --pmc FETCH_
                      "per MI355X_MICROARCH.md (calibrated on k_mask4: it reads the input exactly once), WRITE_SIZE x1024" % tag}
 for d in sorted(glob.glob(os.path.join(src, "*", ""))):
     name = os.path.basename(d.rstrip("/"))
-    if not os.path.exists(os.path.join(d, "traffic.json")):
+    if not os.path.exists(os.path.join(d, "traffic.json")) or name.startswith("side_"):  # (the neighbours' kernels: below)
         continue
     shutil.copy(os.path.join(d, "summary.txt"), os.path.join(dst, name + "_summary.txt"))
     shutil.copy(os.path.join(d, "kernel_stats.csv"), os.path.join(dst, name + "_kernel_stats.csv"))
