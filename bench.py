@@ -8,6 +8,8 @@ depth, distance map, NN index map) written to HBM.  N>1: one process per GPU, ea
 frames (frames are independent: no data-path collective; "scaling": "weak"), timing bracketed by a
 barrier + synchronize, MAX over ranks.  `python bench.py --gpus N` without a launcher starts the N
 ranks itself (torch.distributed.run as a child process, before this process touches a GPU).
+Untimed, in this order: a spin-up until the pass time has settled (300 to 3000 passes, `spinup_passes` in the line: the GPU
+runs its first few hundred passes after an idle spell slower), the W warm-up steps, then exactly K timed steps.
 
 Prints ONE JSON line on rank 0, with
   roofline      the slowest kernel of the pass, timed with HIP events on the launch stream:
@@ -44,7 +46,7 @@ PKG = "distancetransform-depthcompletion_amd"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_PIXEL = 16   # read f32 depth, write f32 depth + f32 distance + i32 index
 EXTRA_WORKLOADS = ("kitti_b32_scanline", "nyu_b64", "synth2048_b16")
-XSTEPS = 50  # timed passes of the extra workloads (behind a warm-up that runs until their pass time has settled)
+XSTEPS = 50  # timed passes of the extra workloads (behind the spin-up and 10 warm-up passes)
 
 
 def host_cores():
@@ -104,25 +106,25 @@ def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, w
     """W untimed passes, then exactly `steps` timed ones between barrier + synchronize; per-kernel HIP-event
     times from a few instrumented passes.  Returns (line fields, roofline dict)."""
     B, H, W = x.shape
-    if warmup is None:
-        # no --warmup given: warm up until the pass time has settled (the first few hundred passes after an idle spell run slower:
-        # clocks, and whatever the process before left behind) -- at least 300 passes, then chunks of 100 until two in a row agree
-        # within 1.5 %, at most 3000.  All of it untimed; the count is reported as "warmup".
-        warmup, prev = 0, None
-        while warmup < 3000:
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(100):
-                op.run(x, path=path)
-            barrier()
-            dt_ = reduce_max(time.perf_counter() - t0)
-            warmup += 100
-            if warmup >= 300 and prev is not None and abs(dt_ - prev) <= 0.015 * prev:
-                break
-            prev = dt_
-    else:
-        for _ in range(warmup):
+    # Spin-up, before the contract's W warm-up steps and just as untimed: the first few hundred passes after an idle spell run
+    # slower (clocks, and whatever the process before left behind: 96 us per pass measured behind 10 passes, 90.7 behind 300
+    # and ever after, once 125 us behind 300 right after a profiler run), and the driver's "--warmup 5 --steps 20" would time
+    # exactly those.  At least 300 passes, then chunks of 100 until two in a row agree within 1.5 %, at most 3000 (0.3 s); the
+    # count is reported as "spinup_passes".  DTFILL_BENCH_NO_SPINUP=1 switches it off.
+    spinup, prev = 0, None
+    while spinup < 3000 and not os.environ.get("DTFILL_BENCH_NO_SPINUP"):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(100):
             op.run(x, path=path)
+        barrier()
+        dt_ = reduce_max(time.perf_counter() - t0)
+        spinup += 100
+        if spinup >= 300 and prev is not None and abs(dt_ - prev) <= 0.015 * prev:
+            break
+        prev = dt_
+    for _ in range(warmup):
+        op.run(x, path=path)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -186,7 +188,7 @@ def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, w
         "pass_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "pass_traffic": t.get("pass_bytes") if t.get("batch") == B else None,
     }
-    out = {"ms_per_step": round(ms_per_step, 4), "elapsed": elapsed, "warmup_done": warmup, "frames_with_index_error": status_bad,
+    out = {"ms_per_step": round(ms_per_step, 4), "elapsed": elapsed, "spinup_passes": spinup, "frames_with_index_error": status_bad,
            "frames_on_general_path": general_frames}
     if rep:
         srt = sorted(rep)
@@ -198,11 +200,8 @@ def measure(op, torch, x, steps, warmup, path, barrier, reduce_max, repeats=0, w
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: the first few hundred passes after an idle spell run at ramping clocks (96 us per pass with 10 warm-up passes, 90.7
-    # with 300 and ever after; once 125 us behind 300 right after a profiler run): without --warmup the untimed passes go on until
-    # two chunks of 100 agree (measure()); the driver's --warmup W is taken as given
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=None, help="untimed passes before the timed ones (default: until the pass time has settled, 300 to 3000)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed passes right before the timed ones (behind the spin-up, see measure())")
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default: the workload's)")
     ap.add_argument("--workload", default="kitti_b32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -319,7 +318,8 @@ def main():
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
-            "warmup": res["warmup_done"],
+            "warmup": args.warmup,
+            "spinup_passes": res["spinup_passes"],
             "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
@@ -343,7 +343,7 @@ def main():
             for name in EXTRA_WORKLOADS:
                 c = synth.CONFIGS[name]
                 xw = torch.from_numpy(synth.make(name)).to(dev)
-                r, rf = measure(op, torch, xw, XSTEPS, None, args.path, barrier, reduce_max, workload=name, traffic=traffic)
+                r, rf = measure(op, torch, xw, XSTEPS, 10, args.path, barrier, reduce_max, workload=name, traffic=traffic)
                 wl[name] = {"value": round(c["B"] * XSTEPS / r["elapsed"], 1), "unit": "frames/s", "frames": c["B"],
                             "shape": [c["H"], c["W"]], "ms_per_step": r["ms_per_step"], "roofline": rf,
                             "frames_on_general_path": r["frames_on_general_path"]}
@@ -355,7 +355,7 @@ def main():
             for name in (args.workload,) + tuple(EXTRA_WORKLOADS):
                 c = synth.CONFIGS[name]
                 xw = x if name == args.workload else torch.from_numpy(synth.make(name)).to(dev)
-                r, rf = measure(op2, torch, xw, XSTEPS, None, "auto", barrier, reduce_max, workload=name + "_l2", traffic=traffic)
+                r, rf = measure(op2, torch, xw, XSTEPS, 10, "auto", barrier, reduce_max, workload=name + "_l2", traffic=traffic)
                 l2[name] = {"value": round(xw.shape[0] * XSTEPS / r["elapsed"], 1), "unit": "frames/s", "frames": int(xw.shape[0]),
                             "ms_per_step": r["ms_per_step"], "roofline": rf}
                 del xw
