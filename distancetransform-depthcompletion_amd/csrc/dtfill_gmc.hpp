@@ -8,8 +8,12 @@
 // (net.py:91-93).  mask == nullptr: the mask is (data > 0.001f), what the reference feeds to the next step
 // (net.py:95-96).  float32; the sum runs over the taps in row-major order, a new maximum restarts it, so
 // the additions are exactly those of "sum over the selected taps in order".
-// One block per 16 x 64 tile; data and mask tiles with a (ts-1)/2 halo in LDS.
+// One block per 16 x 64 tile; data and mask tiles with a (ts-1)/2 halo in LDS.  (GM_TW = 128 fetches a third less -- a staged
+// row segment of 134 floats straddles five 128-byte lines for its four, one of 70 four for two -- and takes the same time on the
+// KITTI crop: the first step is bound by its instructions.  64 divides 1216.)
 constexpr int GM_TH = 16, GM_TW = 64, GM_MAXHALF = 7;
+constexpr int GM_NCW = GM_TW / 64;  // 64-column groups of a tile row: a wave works on one (row, group) at a time, a lane per column
+static_assert(GM_TW % 64 == 0, "whole groups");
 
 // table_size 7 (every model of the reference), compile-time unrolled, ONE pass over the 49 taps: a new window
 // maximum restarts sum and count, an equal value extends them -- the additions performed are exactly "sum
@@ -39,18 +43,18 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
     const int b = blockIdx.z, r0 = blockIdx.y * GM_TH, c0 = blockIdx.x * GM_TW;
     const size_t fo = (size_t)b * H * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ u32 s_mb[PH][4];  // bit c of a row: the mask of padded column c is not zero
+    __shared__ u32 s_mb[PH][2 * GM_NCW + 2];  // bit c of a row: the mask of padded column c is not zero
     bool odd = false;            // a mask value that is neither 0 nor 1 (only a caller's mask can hold one)
     {
         // every load of the thread first (independent: one round trip), then the tile and the mask bits
         constexpr int NR = (PH + 3) / 4;
-        float lv[NR][2], lm[NR][2];
+        float lv[NR][GM_NCW + 1], lm[NR][GM_NCW + 1];
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             // (clamped addresses, unconditional loads: what lies outside the image is dropped below)
             const int gi = min(max(r0 + wave + 4 * q - half, 0), H - 1);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k <= GM_NCW; ++k) {
                 const int gj = min(max(c0 + lane + 64 * k - half, 0), W - 1);
                 const u32 at = (u32)gi * (u32)W + (u32)gj;
                 lv[q][k] = data[fo + at];
@@ -62,9 +66,9 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
             const int r = wave + 4 * q, gi = r0 + r - half;
             if (r >= PH) break;  // wave-uniform
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k <= GM_NCW; ++k) {
                 const int c = lane + 64 * k, gj = c0 + c - half;
-                const bool in = gi >= 0 && gi < H && gj >= 0 && gj < W;
+                const bool in = c < PW && gi >= 0 && gi < H && gj >= 0 && gj < W;
                 const float v = in ? lv[q][k] : 0.0f;
                 const float m = DERIVED ? (v > 0.001f ? 1.0f : 0.0f) : (in ? lm[q][k] : 0.0f);
                 if (c < PW) {
@@ -73,14 +77,9 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
                 }
                 odd |= !(m == 0.0f || m == 1.0f);
                 const u64 bal = __ballot(m != 0.0f);
-                if (lane == 0) {
-                    if (k == 0) {
-                        s_mb[r][0] = (u32)bal;
-                        s_mb[r][1] = (u32)(bal >> 32);
-                    } else {
-                        s_mb[r][2] = (u32)bal;
-                        s_mb[r][3] = 0u;
-                    }
+                if (lane == 0) {  // (the last group holds the six columns beyond the tile's: the lanes past them ballot 0)
+                    s_mb[r][2 * k] = (u32)bal;
+                    s_mb[r][2 * k + 1] = (u32)(bal >> 32);
                 }
             }
         }
@@ -89,25 +88,25 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
     // With a 0 / 1 mask: the L1 distance of every pixel's nearest masked tap, 64 pixels of a row at a time.  E_k of a padded row:
     // bit c = a masked tap within k columns of pixel c; "nearest tap within t" of an output row = the OR over its seven rows of
     // E_(t - |di|); seven cumulative words per row, kept as the three bit planes of n = 7 - distance (0: no masked tap).
-    __shared__ u64 s_E[PH][4], s_N[GM_TH][3];
+    __shared__ u64 s_E[PH][GM_NCW][4], s_N[GM_TH][GM_NCW][3];
     if (binary) {
-        if (threadIdx.x < PH) {
-            const int rr = threadIdx.x;
-            const u64 lo = (u64)s_mb[rr][0] | (u64)s_mb[rr][1] << 32, hi = (u64)s_mb[rr][2];
-            auto S = [&](int x) { return lo >> x | hi << (64 - x); };  // the mask bits of padded columns c + x
+        if (threadIdx.x < PH * GM_NCW) {
+            const int rr = threadIdx.x / GM_NCW, h = threadIdx.x % GM_NCW;  // padded row, column group
+            const u64 lo = (u64)s_mb[rr][2 * h] | (u64)s_mb[rr][2 * h + 1] << 32, hi = (u64)s_mb[rr][2 * h + 2] | (u64)s_mb[rr][2 * h + 3] << 32;
+            auto S = [&](int x) { return lo >> x | hi << (64 - x); };  // the mask bits of padded columns 64 h + c + x
             const u64 e0 = S(3), e1 = e0 | S(2) | S(4), e2 = e1 | S(1) | S(5), e3 = e2 | lo | S(6);
-            s_E[rr][0] = e0; s_E[rr][1] = e1; s_E[rr][2] = e2; s_E[rr][3] = e3;
+            s_E[rr][h][0] = e0; s_E[rr][h][1] = e1; s_E[rr][h][2] = e2; s_E[rr][h][3] = e3;
         }
         __syncthreads();
-        if (threadIdx.x < GM_TH) {
-            const int r = threadIdx.x;  // output row r: padded rows r .. r + 6, centre r + 3
-            auto E = [&](int k, int d) { return d ? s_E[r + 3 - d][k] | s_E[r + 3 + d][k] : s_E[r + 3][k]; };
+        if (threadIdx.x < GM_TH * GM_NCW) {
+            const int r = threadIdx.x / GM_NCW, h = threadIdx.x % GM_NCW;  // output row r: padded rows r .. r + 6, centre r + 3
+            auto E = [&](int k, int d) { return d ? s_E[r + 3 - d][h][k] | s_E[r + 3 + d][h][k] : s_E[r + 3][h][k]; };
             const u64 t0 = E(0, 0), t1 = E(1, 0) | E(0, 1), t2 = E(2, 0) | E(1, 1) | E(0, 2), t3 = E(3, 0) | E(2, 1) | E(1, 2) | E(0, 3),
                       t4 = E(3, 0) | E(3, 1) | E(2, 2) | E(1, 3), t5 = E(3, 0) | E(3, 1) | E(3, 2) | E(2, 3),
                       t6 = E(3, 0) | E(3, 1) | E(3, 2) | E(3, 3);
-            s_N[r][2] = t3;
-            s_N[r][1] = (t5 & ~t3) | t1;
-            s_N[r][0] = (t6 & ~t5) | (t4 & ~t3) | (t2 & ~t1) | t0;
+            s_N[r][h][2] = t3;
+            s_N[r][h][1] = (t5 & ~t3) | t1;
+            s_N[r][h][0] = (t6 & ~t5) | (t4 & ~t3) | (t2 & ~t1) | t0;
         }
         __syncthreads();
     }
@@ -140,7 +139,9 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
         const int w = c >> 5;
 #pragma unroll
         for (int i = 0; i < 7; ++i) mbits[i] = __builtin_amdgcn_alignbit(s_mb[r + i][w + 1], s_mb[r + i][w], (u32)c) & 0x7Fu;  // taps j = 0..6: bits 0..6
-        const u32 n = (u32)((s_N[r][0] >> c) & 1ull) | (u32)((s_N[r][1] >> c) & 1ull) << 1 | (u32)((s_N[r][2] >> c) & 1ull) << 2;
+        const u64 *np = s_N[r][c >> 6];
+        const int cb = c & 63;
+        const u32 n = (u32)((np[0] >> cb) & 1ull) | (u32)((np[1] >> cb) & 1ull) << 1 | (u32)((np[2] >> cb) & 1ull) << 2;
         const u32 tmin = n ? 7u - n : 64u;
         float acc = 0.0f, cnt = 0.0f;
         if (tmin >= 64u) {
@@ -191,20 +192,23 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
     __syncthreads();
     if (!DERIVED) {
         if (!binary) {
-            for (int r = wave; r < GM_TH; r += 4)
-                if (r0 + r < H && c0 + lane < W) full(r, lane);
+            for (int u = wave; u < GM_TH * GM_NCW; u += 4) {  // a wave per (row, column group)
+                const int r = u / GM_NCW, c = 64 * (u % GM_NCW) + lane;
+                if (r0 + r < H && c0 + c < W) full(r, c);
+            }
             return;
         }
         // the pixels without a masked tap in their window (8 % at 5 % density: nearly every wave holds one) are listed and
         // summed afterwards, 64 of them per wave, instead of every wave walking through the 49 taps for its one or two
-        for (int r = wave; r < GM_TH; r += 4) {
-            const bool in = r0 + r < H && c0 + lane < W;
-            const bool none = in && ring(r, lane, std::false_type{});
+        for (int u = wave; u < GM_TH * GM_NCW; u += 4) {
+            const int r = u / GM_NCW, c = 64 * (u % GM_NCW) + lane;
+            const bool in = r0 + r < H && c0 + c < W;
+            const bool none = in && ring(r, c, std::false_type{});
             const u64 bal = __ballot(none);
             int base = 0;
             if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (none) s_list[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (u16)(r * GM_TW + lane);
+            if (none) s_list[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (u16)(r * GM_TW + c);
         }
         __syncthreads();
         const int n49 = s_n;
@@ -214,15 +218,16 @@ __global__ __launch_bounds__(256) void k_gmc7(const float *__restrict__ data, co
         }
         return;
     }
-    for (int r = wave; r < GM_TH; r += 4) {
-        const bool in = r0 + r < H && c0 + lane < W;
-        const float vc = s_d[(r + 3) * PW + lane + 3];
+    for (int u = wave; u < GM_TH * GM_NCW; u += 4) {
+        const int r = u / GM_NCW, c = 64 * (u % GM_NCW) + lane;
+        const bool in = r0 + r < H && c0 + c < W;
+        const float vc = s_d[(r + 3) * PW + c + 3];
         const bool easy = in && vc > 0.001f;  // (its value went out with the previous step's)
         const u64 bal = __ballot(in && !easy);
         int base = 0;
         if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (in && !easy) s_list[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (u16)(r * GM_TW + lane);
+        if (in && !easy) s_list[base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u))] = (u16)(r * GM_TW + c);
     }
     __syncthreads();
     const int n = s_n;
