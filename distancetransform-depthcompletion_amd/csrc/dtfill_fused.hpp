@@ -142,12 +142,14 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     const int src_base = wr0 * W + wc0;  // frame offset of window cell (0,0) (may be negative)
     const u32 last_px = (u32)(H * W - 1);
     bool overflow = false;
-    // Tile pixels in raster order over the threads: pixel p = pb + e * NT + tid, so every batch but the last
-    // has all lanes busy whatever th x tw is, and a wave's stores are runs of consecutive pixels.
+    // A lane walks F_EB pixels of ONE column, rows 8 g .. 8 g + 7 of the tile: slot L = sb + tid is (row group g, column) =
+    // divmod(L, tw), so the index arithmetic is done once per slot and the F_EB pixels differ by a row pitch each; a wave's store
+    // is still a run of 64 consecutive pixels of a row (two runs where the slots wrap into the next group).
     // Software pipeline: the gathers of one batch stay in flight during the walk of the next batch (LDS only);
     // a batch's stores are issued just before the next batch's gathers.
-    const int npx = th * tw;
+    const int nslots = ((th + F_EB - 1) / F_EB) * tw;
     const float inv_tw = 1.0f / (float)tw;
+    const u32 w4 = (u32)W << 2;
     int p_lab[F_EB], p_dd[F_EB];  // the batch whose gathers are in flight
     u32 p_opix[F_EB];
     float p_val[F_EB];
@@ -175,26 +177,31 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             }
         }
     };
-    for (int pb = 0; pb < npx; pb += NT * F_EB) {
+    for (int sb = 0; sb < nslots; sb += NT) {
         int pos[F_EB], code[F_EB];  // pos = row * F_P + col: byte index in s_par
         u32 home[F_EB];             // window row << 16 | window column of the walker's own pixel
         u32 opix[F_EB];
         u32 ok = 0;
+        {
+            const int L = sb + (int)threadIdx.x, Lc = min(L, nslots - 1);
+            // L / tw: (L + 0.5) / tw is at least 0.5 / tw away from an integer, far above float rounding
+            // for L < 2^14, tw < 2^8
+            const int g = (int)(((float)Lc + 0.5f) * inv_tw);
+            const int tc = Lc - __mul24(g, tw), trb = g * F_EB;
+            const u32 home0 = (u32)(FR + trb) << 16 | (u32)(FR + tc);
+            const u32 opix0 = (u32)(__mul24(r0 + trb, W) + c0 + tc) << 2;  // byte offset; 24-bit multiplies are full rate (H, W < 8192)
+            const int pos0 = __mul24(FR + trb, F_P) + FR + tc;
 #pragma unroll
-        for (int e = 0; e < F_EB; ++e) {
-            const int p = pb + e * NT + (int)threadIdx.x;
-            const int pc = min(p, npx - 1);
-            // p / tw: (p + 0.5) / tw is at least 0.5 / tw away from an integer, far above float rounding
-            // for p < 2^14, tw < 2^8
-            const int tr = (int)(((float)pc + 0.5f) * inv_tw);
-            const int tc = pc - __mul24(tr, tw);
-            home[e] = (u32)(FR + tr) << 16 | (u32)(FR + tc);
-            opix[e] = (u32)(__mul24(r0 + tr, W) + c0 + tc) << 2;  // byte offset; 24-bit multiplies are full rate (H, W < 8192)
-            pos[e] = __mul24(FR + tr, F_P) + FR + tc;
-            code[e] = s_par[pos[e]];
-            ok |= (p < npx && code[e] != F_NONE) ? (1u << e) : 0u;
-            // undecidable here: the any-distance kernels take the pixel's row (found again below, off the common path)
-            overflow |= p < npx && code[e] == F_NONE;
+            for (int e = 0; e < F_EB; ++e) {
+                const bool valid = L < nslots && trb + e < th;  // (rows past the tile: still cells of the window, read and dropped)
+                home[e] = home0 + ((u32)e << 16);
+                opix[e] = opix0 + (u32)e * w4;
+                pos[e] = pos0 + e * F_P;
+                code[e] = s_par[pos[e]];
+                ok |= (valid && code[e] != F_NONE) ? (1u << e) : 0u;
+                // undecidable here: the any-distance kernels take the pixel's row (found again below, off the common path)
+                overflow |= valid && code[e] == F_NONE;
+            }
         }
         // Unconditional hops: sources and undecided cells carry the step (0,0), so a walker that has
         // arrived just stays.  No selects, no divergent control flow -- the reads of the F_EB walkers
@@ -266,14 +273,15 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     // depth is already cropped / floored).  Rare, so a wave that met one looks for its rows only now (s_par is still there).
     if (any && !EPI) {
         u32 *rowflag = rowflag_of(fflag, (int)gridDim.y);  // the workspace keeps the row flags right behind the frame flags
-        for (int p = threadIdx.x; p < npx; p += NT) {
-            const int tr = p / tw, tc = p - tr * tw;
-            if (s_par[__mul24(FR + tr, F_P) + FR + tc] == F_NONE) {
-                rowflag[(size_t)b * H + r0 + tr] = 1u;  // same-value race
-                // one of the two rows k_sky starts from: the any-distance kernels take the sky's rows as well
-                const int s0 = finfo[b * FI_STRIDE + FI_SKY0];
-                if (s0 > 0 && (r0 + tr == s0 || r0 + tr == s0 + 1)) finfo[b * FI_STRIDE + FI_SKY] = 0;
-            }
+        for (int L = threadIdx.x; L < nslots; L += NT) {  // the slots this thread walked above
+            const int g = L / tw, tc = L - g * tw;
+            for (int tr = g * F_EB; tr < min(g * F_EB + F_EB, th); ++tr)
+                if (s_par[__mul24(FR + tr, F_P) + FR + tc] == F_NONE) {
+                    rowflag[(size_t)b * H + r0 + tr] = 1u;  // same-value race
+                    // one of the two rows k_sky starts from: the any-distance kernels take the sky's rows as well
+                    const int s0 = finfo[b * FI_STRIDE + FI_SKY0];
+                    if (s0 > 0 && (r0 + tr == s0 || r0 + tr == s0 + 1)) finfo[b * FI_STRIDE + FI_SKY] = 0;
+                }
         }
     }
     return any;
