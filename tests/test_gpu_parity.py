@@ -786,6 +786,22 @@ def test_generate_multi_channel_vs_oracle(pkg, oracle):
             assert (g is None) == (w is None) and (g is None or np.array_equal(g, w, equal_nan=True))
 
 
+def test_rows_handed_on_for_every_tile_height(gpu_op, oracle):
+    """The window kernel walks its tile in groups of eight rows per lane and looks for the rows it has to hand on (a pixel
+    farther than the halo from every source) by the same slots: every height modulo 8, a band of columns without sources wide
+    enough that some rows -- not all -- hold such a pixel, and the same under an empty top half (found by the seeded random test
+    when the hand-over still scanned the pixels in raster order)."""
+    rng = np.random.default_rng(5150)
+    for H in list(range(1, 20)) + [23, 24, 25, 87, 88, 89, 95, 96, 97]:
+        W = int(rng.integers(120, 200))
+        x = np.where(rng.random((2, H, W)) < 0.03, rng.uniform(0.95, 80, (2, H, W)), 0).astype(np.float32)
+        x[:, :, W // 3 :] = 0                                  # distances up to 2 W / 3 on the right
+        x[1, rng.integers(0, H), W - 1 - int(rng.integers(0, 30))] = 7.0   # one source in the band: only some rows stay far
+        if H > 4:
+            x[0, : H // 2] = 0
+        assert_equal_to_oracle(oracle, gpu_op, x)
+
+
 def test_shape_errors(gpu_op, pkg):
     import torch
 
