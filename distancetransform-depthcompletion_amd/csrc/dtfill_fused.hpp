@@ -191,9 +191,10 @@ __device__ __forceinline__ bool fused_walk_epilogue(
             const u32 home0 = (u32)(FR + trb) << 16 | (u32)(FR + tc);
             const u32 opix0 = (u32)(__mul24(r0 + trb, W) + c0 + tc) << 2;  // byte offset; 24-bit multiplies are full rate (H, W < 8192)
             const int pos0 = __mul24(FR + trb, F_P) + FR + tc;
+            const int nv = L < nslots ? th - trb : 0;  // the slot's rows inside the tile (the rest: still cells of the window, read and dropped)
 #pragma unroll
             for (int e = 0; e < F_EB; ++e) {
-                const bool valid = L < nslots && trb + e < th;  // (rows past the tile: still cells of the window, read and dropped)
+                const bool valid = e < nv;
                 home[e] = home0 + ((u32)e << 16);
                 opix[e] = opix0 + (u32)e * w4;
                 pos[e] = pos0 + e * F_P;
@@ -233,9 +234,11 @@ __device__ __forceinline__ bool fused_walk_epilogue(
 #pragma unroll
         for (int e = 0; e < F_EB; ++e) {
             // a decided chain ends on a source inside the in-image window
-            // pos / F_P in float: (pos + 0.5) / F_P is >= 0.5 / F_P away from an integer, pos < 2^15 (three full-rate
-            // instructions; the integer division is a quarter-rate v_mul_hi_u32)
-            const int pr_ = (int)(((float)pos[e] + 0.5f) * (1.0f / (float)F_P)), pc_ = pos[e] - __mul24(pr_, F_P);
+            // pos / F_P by a 24-bit multiply: 196 * 5350 / 2^20 = 1 + 2.3e-5, pos / 196 < 128, so the product is at most 0.003 above
+            // the quotient, whose fraction is at most 195 / 196: same integer part (three full-rate instructions with the remainder;
+            // the integer division is a quarter-rate v_mul_hi_u32)
+            static_assert(F_P == 196 && F_WHM * F_P < (1 << 15), "the reciprocal below is F_P's");
+            const int pr_ = (int)(__umul24((u32)pos[e], 5350u) >> 20), pc_ = pos[e] - __mul24(pr_, F_P);
             // L1 distance to the nearest source IS d: |drow| + |dcol| of the two 16-bit halves in one instruction
             dd[e] = (int)__builtin_amdgcn_sad_u16((u32)pr_ << 16 | (u32)pc_, home[e], 0u);
             const int bitpos = sh + pc_;  // bit index in the row's image-aligned bit string, from word w0
