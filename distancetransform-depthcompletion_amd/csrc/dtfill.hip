@@ -274,18 +274,23 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const int ovec = (ten ? ((W & 1) == 0 && aligned(dt, 8)) : ((W & 3) == 0 && aligned(dt, 16))) |
                          (((W & 31) == 0 && dt && aligned(dt, 128)) ? 2 : 0);
         const size_t rlds = (ovec & 2) ? (size_t)W * sizeof(float) : 0;
-        const dim3 grid(H, B);
-#define LAUNCH_ROWS(PPL_, MAXT_)                                                                                      \
-    k_rows<PPL_, MAXT_><<<grid, 64 * nwv, rlds, st>>>(c.ct, c.ctp, c.fflag2, H, W, nb, Wp, c.planes, c.plane_bytes, dt,    \
-                                                   fin ? c.spix : nullptr, ovec, c.rowfar, c.finfo)
-        if (ten && nwv <= 4)
-            LAUNCH_ROWS(10, 256);
+        const int rpb = nwv == 1 ? R_RPB : 1;  // rows per block: several where a row is one wave (the exit of a frame that has none costs a block dispatch per row)
+        const dim3 grid((H + rpb - 1) / rpb, B);
+#define LAUNCH_ROWS(PPL_, MAXT_, MULTI_)                                                                                        \
+    k_rows<PPL_, MAXT_, MULTI_><<<grid, 64 * nwv, rlds, st>>>(c.ct, c.ctp, c.fflag2, H, W, nb, Wp, c.planes, c.plane_bytes, dt, \
+                                                           fin ? c.spix : nullptr, ovec, c.rowfar, c.finfo, rpb)
+        if (rpb > 1 && ten)  // (rows of a single wave)
+            LAUNCH_ROWS(10, 256, true);
+        else if (rpb > 1)
+            LAUNCH_ROWS(8, 256, true);
+        else if (ten && nwv <= 4)
+            LAUNCH_ROWS(10, 256, false);
         else if (ten)
-            LAUNCH_ROWS(10, 1024);
+            LAUNCH_ROWS(10, 1024, false);
         else if (nwv <= 4)
-            LAUNCH_ROWS(8, 256);
+            LAUNCH_ROWS(8, 256, false);
         else
-            LAUNCH_ROWS(8, 1024);
+            LAUNCH_ROWS(8, 1024, false);
 #undef LAUNCH_ROWS
         mark();
         // the frames with a handful of sources (k_frame: ROUTE_POINTS, fflag 3; only with the row flags) ride in k_fin's launch:

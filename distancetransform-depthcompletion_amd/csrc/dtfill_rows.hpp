@@ -268,18 +268,17 @@ constexpr int R_MAXPW = 256;   // 32-pixel words per row: W <= 8191
 // within R_MARGIN of a core row; everything further away keeps k_fused's results.
 constexpr int R_MARGIN = 10;
 
-template <int PPL, int MAXT>  // MAXT: 256 (rows of up to 4 waves; 3 waves per SIMD) or 1024 (any row the shape limit allows)
-__global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
-    const uint2 *__restrict__ ct, int CTP, const int *__restrict__ fflag, int H, int W, int nb, int Wp,
+constexpr int R_RPB = 4;  // rows per block (one after the other, a grid apart) where a row is a single wave's: a frame that is none of
+                          // these kernels' then costs a quarter of the block dispatches (NYU: 30 720 blocks of 64 threads, 3.4 us)
+
+template <int PPL>
+__device__ __forceinline__ void rows_body(
+    const uint2 *__restrict__ ct, int CTP, int ff, int H, int W, int nb, int Wp,
     u8 *__restrict__ planes, size_t plane_bytes, float *__restrict__ out_dt, u32 *__restrict__ spix_out, int ovec,
-    const u32 *__restrict__ rowflag, const int *__restrict__ finfo_sky) {
+    const u32 *__restrict__ rowflag, const int *__restrict__ finfo_sky, int i, int b, u32 (*__restrict__ s_tot)[6],
+    u32 (*__restrict__ s_bits)[R_MAXPW + 1]) {
     static_assert(PPL == 8 || PPL == 10, "loads and stores below are written for 8 or 10 columns per lane");
-    __shared__ u32 s_tot[R_MAXWV][6];
-    __shared__ u32 s_bits[5][R_MAXPW + 1];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
-    const int i = blockIdx.x, b = blockIdx.y;
-    const int ff = fflag[b];
-    if (!ff || ff == 3) return;  // block-uniform (3: k_pts's frame)
     if (ff == 1) {    // only near a row k_fused could not finish
         const int rr = i - R_MARGIN + lane;
         const int sky_live = finfo_sky[b * FI_STRIDE + FI_SKY];
@@ -477,6 +476,32 @@ __global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(
     for (int k = threadIdx.x; k < 5 * wpr; k += blockDim.x) {  // the row's plane words leave as whole words
         const int p = k / wpr, w = k - p * wpr;
         reinterpret_cast<u32 *>(planes + p * plane_bytes + ((size_t)b * H + i) * Wp)[w] = s_bits[p][w];
+    }
+}
+
+template <int PPL, int MAXT, bool MULTI>  // MAXT: 256 (rows of up to 4 waves; 3 waves per SIMD) or 1024 (any row the shape limit allows)
+__global__ __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1) void k_rows(  // MULTI: rpb rows per block (the loop costs 17 VGPR: its own instance)
+   
+    const uint2 *__restrict__ ct, int CTP, const int *__restrict__ fflag, int H, int W, int nb, int Wp,
+    u8 *__restrict__ planes, size_t plane_bytes, float *__restrict__ out_dt, u32 *__restrict__ spix_out, int ovec,
+    const u32 *__restrict__ rowflag, const int *__restrict__ finfo_sky, int rpb) {
+    __shared__ u32 s_tot[R_MAXWV][6];
+    __shared__ u32 s_bits[5][R_MAXPW + 1];
+    const int b = blockIdx.y;
+    const int ff = fflag[b];
+    if (!ff || ff == 3) return;  // block-uniform (3: k_pts's frame)
+    if (!MULTI) {
+        rows_body<PPL>(ct, CTP, ff, H, W, nb, Wp, planes, plane_bytes, out_dt, spix_out, ovec, rowflag, finfo_sky, (int)blockIdx.x, b, s_tot, s_bits);
+        return;
+    }
+    // rows blockIdx.x, + gridDim.x, ...: rpb of them, a grid apart so that the rows around a handed-on row stay spread over the
+    // blocks
+#pragma unroll 1
+    for (int k = 0; k < rpb; ++k) {
+        const int i = (int)blockIdx.x + k * (int)gridDim.x;
+        if (i >= H) break;
+        rows_body<PPL>(ct, CTP, ff, H, W, nb, Wp, planes, plane_bytes, out_dt, spix_out, ovec, rowflag, finfo_sky, i, b, s_tot, s_bits);
+        __syncthreads();  // the next row reuses the block's LDS
     }
 }
 
