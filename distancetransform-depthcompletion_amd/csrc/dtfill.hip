@@ -274,12 +274,14 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const int ovec = (ten ? ((W & 1) == 0 && aligned(dt, 8)) : ((W & 3) == 0 && aligned(dt, 16))) |
                          (((W & 31) == 0 && dt && aligned(dt, 128)) ? 2 : 0);
         const size_t rlds = (ovec & 2) ? (size_t)W * sizeof(float) : 0;
-        const int rpb = nwv == 1 ? R_RPB : 1;  // rows per block: several where a row is one wave (the exit of a frame that has none costs a block dispatch per row)
+        // rows per block: several where a row is one wave, or where there are very many rows (the exit of a frame that has none, or of
+        // a row far from every handed-on row, costs a block dispatch per row)
+        const int rpb = (nwv == 1 || (long long)H * B >= 16384) && nwv <= 4 ? R_RPB : 1;
         const dim3 grid((H + rpb - 1) / rpb, B);
 #define LAUNCH_ROWS(PPL_, MAXT_, MULTI_)                                                                                        \
     k_rows<PPL_, MAXT_, MULTI_><<<grid, 64 * nwv, rlds, st>>>(c.ct, c.ctp, c.fflag2, H, W, nb, Wp, c.planes, c.plane_bytes, dt, \
                                                            fin ? c.spix : nullptr, ovec, c.rowfar, c.finfo, rpb)
-        if (rpb > 1 && ten)  // (rows of a single wave)
+        if (rpb > 1 && ten)
             LAUNCH_ROWS(10, 256, true);
         else if (rpb > 1)
             LAUNCH_ROWS(8, 256, true);
