@@ -231,7 +231,7 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         // streaming stores only where every run of tile pixels a wave stores is whole 128-byte lines
         auto line = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 127) == 0; };
         const bool stream = (W & 31) == 0 && (t16.TW & 31) == 0 && (t32.TW & 31) == 0 && line(out_depth) && line(out_dt) && line(out_index);
-        const dim3 fg(max(t16.ntiles, t32.ntiles), B);
+        const dim3 fg(B, max(t16.ntiles, t32.ntiles));  // frames along x: a frame's tiles beyond its own tiling (they exit) come last
         if (stream)
             k_fused<true><<<fg, F_NT, 0, st>>>(x, c.srcbits, c.wpre_s, c.rowbase_s, c.finfo, c.vlist, H, W, Wd, t16, t32, out_depth, out_dt,
                                                out_index, c.route, c.fflag2, status, ep);

@@ -275,7 +275,7 @@ __device__ __forceinline__ bool fused_walk_epilogue(
     // same values again).  With a depth epilogue the whole frame is (its chains may end on finished pixels whose stored
     // depth is already cropped / floored).  Rare, so a wave that met one looks for its rows only now (s_par is still there).
     if (any && !EPI) {
-        u32 *rowflag = rowflag_of(fflag, (int)gridDim.y);  // the workspace keeps the row flags right behind the frame flags
+        u32 *rowflag = rowflag_of(fflag, (int)gridDim.x);  // the workspace keeps the row flags right behind the frame flags (gridDim.x = frames)
         for (int L = threadIdx.x; L < nslots; L += NT) {  // the slots this thread walked above
             const int g = L / tw, tc = L - g * tw;
             for (int tr = g * F_EB; tr < min(g * F_EB + F_EB, th); ++tr)
@@ -305,8 +305,9 @@ __device__ __forceinline__ void fused_body(bool premarked,
     int *__restrict__ fflag, int *__restrict__ frame_status, const DepthEpilogue ep, u32 *__restrict__ s_ring, uint2 *__restrict__ s_rw,
     short *__restrict__ s_tab, u32 (*__restrict__ s_any)[F_NT / 64]) {
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    // (frames along x, tiles along y: the tiles beyond a frame's own tiling, which exit, are dispatched after every working block)
+    const int b = blockIdx.x;
+    const int ty = blockIdx.y / tiles_x, tx = blockIdx.y - ty * tiles_x;
     // the tile rows split the rows from FI_TR0 on evenly (k_frame: 0, or the first source row under a sky)
     const int tbase = finfo[b * FI_STRIDE + FI_TR0];
     const int TH = (H - tbase + nty - 1) / nty;
@@ -319,7 +320,7 @@ __device__ __forceinline__ void fused_body(bool premarked,
         // k_frame handed rows of this frame to the any-distance kernels up front (the empty sky): the tile shrinks to the span
         // of its rows that are still this kernel's; a tile without any is done.  (A row another block marks meanwhile is
         // redone whole as well: whether this block still stores its part of it does not matter.)
-        const u32 *rowflag = rowflag_of(fflag, (int)gridDim.y) + (size_t)b * H;
+        const u32 *rowflag = rowflag_of(fflag, (int)gridDim.x) + (size_t)b * H;
         if (tid == 0) {
             s_any[0][0] = 0xFFFFFFFFu;
             s_any[0][1] = 0u;
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
     uint2 *s_rw = reinterpret_cast<uint2 *>(s_raw + F_OFF_RW);
     short *s_tab = reinterpret_cast<short *>(s_raw + F_OFF_TAB);  // s_par displacement of the step enc (0 for the codes that are no step)
     u32(*s_any)[F_NT / 64] = reinterpret_cast<u32(*)[F_NT / 64]>(s_raw + F_OFF_ANY);  // per wave: did level t produce anything (double-buffered by level parity)
-    const int rt = route[blockIdx.y];        // block-uniform
+    const int rt = route[blockIdx.x];        // block-uniform
     if (rt == ROUTE_POINTS) return;  // a frame with a handful of sources: k_pts's tiles ride in k_fin's launch (dtfill_pts.hpp)
     const int r = rt > 0 ? (rt & 0xFF) : 0;
     const bool pre = rt > 0 && (rt & ROUTE_PREMARK);
@@ -603,12 +604,12 @@ __global__ __launch_bounds__(F_NT, 4) void k_fused(
 #define FUSED_CALL(FR_, EPI_, T_)                                                                                        \
     fused_body<FR_, EPI_, STREAM && !(EPI_)>(pre, x, srcbits, wpre_s, rowbase_s, finfo, vlist, H, W, Wd, T_.nty, T_.TW, T_.tiles_x, out_depth, out_dt, \
                           out_index, fflag, frame_status, ep, s_ring, s_rw, s_tab, s_any)
-    if (r == 16 && (int)blockIdx.x < t16.ntiles) {
+    if (r == 16 && (int)blockIdx.y < t16.ntiles) {
         if (epi)
             FUSED_CALL(16, true, t16);
         else
             FUSED_CALL(16, false, t16);
-    } else if (r == 32 && (int)blockIdx.x < t32.ntiles) {
+    } else if (r == 32 && (int)blockIdx.y < t32.ntiles) {
         if (epi)
             FUSED_CALL(32, true, t32);
         else
