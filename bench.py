@@ -368,10 +368,14 @@ def main():
                 batch = xh[:nb, :, :, None]
                 pkg.DT_complete_batch(batch)
                 n = 20 if nb == 1 else 8
-                t0 = time.perf_counter()
-                for _ in range(n):
-                    pkg.DT_complete_batch(batch)
-                e2e["B%d" % nb] = round(nb * n / (time.perf_counter() - t0), 1)
+                runs = []  # five runs of n calls, the median reported (a host hiccup -- the staging threads share the box's
+                for _ in range(5):  # cores with whatever else runs there -- once read 8.5 k for 12.5 k frames/s)
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        pkg.DT_complete_batch(batch)
+                    runs.append(nb * n / (time.perf_counter() - t0))
+                e2e["B%d" % nb] = round(sorted(runs)[2], 1)
+                e2e["B%d_runs" % nb] = [round(v, 1) for v in runs]
             # what one synchronous call cannot beat: its input over the link, the pass, its output (depth only) back
             fb = 4 * H * W
             bound = 1.0 / (fb / (link["h2d"] * 1e9) + res["ms_per_step"] * 1e-3 / B + fb / (link["d2h"] * 1e9))
