@@ -159,13 +159,13 @@ const char *const kNamesL1[NK_L1] = {"k_mask", "k_frame", "k_fused", "k_colT", "
 void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, float val_thr, const Carve &c, unsigned flags,
                  hipStream_t st) {
     const bool vec = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    const dim3 g4((H + 3) / 4, B);
+    const dim3 g4((H + 3) / 4, B), g4m(B, (H + 3) / 4);  // (k_mask4: frames along x)
     // negflag ("this frame holds a negative value", raised by the first outlier launch, read by the second) starts clear whatever
     // the workspace held before
     if (flags & DTFILL_FLAG_OUTLIER_REMOVAL) (void)hipMemsetAsync(c.negflag, 0, (size_t)B * sizeof(int), st);
     if ((flags & DTFILL_FLAG_OUTLIER_REMOVAL) && vec) {
-        k_mask4<1, 1><<<g4, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v, c.negflag);
-        k_mask4<2, 1><<<g4, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v, c.negflag);
+        k_mask4<1, 1><<<g4m, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v, c.negflag);
+        k_mask4<2, 1><<<g4m, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v, c.negflag);
     } else if (flags & DTFILL_FLAG_OUTLIER_REMOVAL) {
         k_mask_o<false><<<g4, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v,
                                             c.negflag);
@@ -173,7 +173,7 @@ void launch_mask(const float *x, int B, int H, int W, int Wd, float src_thr, flo
                                            c.negflag);
     }
     else if (vec)
-        k_mask4<0, 1><<<g4, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v,
+        k_mask4<0, 1><<<g4m, 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits, c.valbits, c.wpre_s, c.wpre_v, c.rowcnt_s, c.rowcnt_v,
                                           c.negflag);
     else
         k_mask<<<dim3((H + 4 * M_RPW - 1) / (4 * M_RPW), B), 256, 0, st>>>(x, H, W, Wd, src_thr, val_thr, c.srcbits,

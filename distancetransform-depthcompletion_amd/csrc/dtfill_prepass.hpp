@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void k_mask4(const float *__restrict__ x, int 
     __shared__ u16 s_list[OM ? 4 : 1][OM ? M4_NC * 256 : 1];
     __shared__ u32 s_drop[OM ? 4 : 1][OM ? M4_NC * 8 : 1];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i0 = (blockIdx.x * 4 + wave) * R, b = blockIdx.y;
+    // (frames along grid x: with a batch of a multiple of eight frames a frame's rows are one XCD's, where the window kernel's blocks of
+    // that frame will look for its bit words)
+    const int i0 = (blockIdx.y * 4 + wave) * R, b = blockIdx.x;
     if (i0 >= H) return;
     if (OM == 2 && !negflag[b]) return;
     bool neg = false;
