@@ -256,8 +256,9 @@ int run_l1(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         if (lds > 48 * 1024)  // (set per call: the attribute belongs to the current device)
             ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_colT), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         const int ncol = (c.ctp + 63) / 64;
-        k_colT<<<dim3(ncol + sky.nblocks, B), 64 * cw, lds, st>>>(c.srcbits, c.fflag2, H, W, Wd, nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s,
-                                                             (out_depth || out_index) ? c.rec : nullptr, ncol, sky);
+        const int fx = cw <= 4;  // frames along grid x for frames of up to 512 rows (k_colT's comment)
+        k_colT<<<fx ? dim3(B, ncol + sky.nblocks) : dim3(ncol + sky.nblocks, B), 64 * cw, lds, st>>>(
+            c.srcbits, c.fflag2, H, W, Wd, nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s, (out_depth || out_index) ? c.rec : nullptr, ncol, sky, fx);
         if (rowflags && !sky_rides)
             k_sky<<<dim3(sky.nstrips * ((H + SKY_RG - 1) / SKY_RG), B), SKY_NT, sky_lds(sky_span_max(H, W)), st>>>(
                 c.finfo, H, W, out_dt, out_dt_caller, out_depth, out_index, sky.nstrips);
@@ -367,8 +368,9 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const size_t lds = colT_lds(c.nb);
         if (lds > 48 * 1024)
             ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_colT), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-        k_colT<<<dim3((c.ctp + 63) / 64, B), 64 * cw, lds, st>>>(c.srcbits, c.fflag2, H, W, Wd, c.nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s,
-                                                         (out_depth || out_index) ? c.rec : nullptr, (c.ctp + 63) / 64, SkyArgs{});
+        const int fx = cw <= 4, ncb = (c.ctp + 63) / 64;  // (frames along grid x for frames of up to 512 rows: k_colT's comment)
+        k_colT<<<fx ? dim3(B, ncb) : dim3(ncb, B), 64 * cw, lds, st>>>(c.srcbits, c.fflag2, H, W, Wd, c.nb, c.ctp, c.ct, c.wpre_s, c.rowbase_s,
+                                                                        (out_depth || out_index) ? c.rec : nullptr, ncb, SkyArgs{}, fx);
     }
     mark();
     {

@@ -57,8 +57,8 @@ __host__ __device__ inline size_t colT_lds(int nb) { return (size_t)nb * 64 * (2
 __device__ __forceinline__ void colT_block(const u64 *__restrict__ srcbits, const int *__restrict__ fflag, int H,
                                            int W, int Wd, int nb, int CTP, uint2 *__restrict__ ct,
                                            const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
-                                           uint4 *__restrict__ rec, int wd, u16 *s_lf, u64 (*s_rowword)[64]) {
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
+                                           uint4 *__restrict__ rec, int wd, int b, u16 *s_lf, u64 (*s_rowword)[64]) {
+    const int lane = threadIdx.x & 63;
     const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
     if (fflag && (!fflag[b] || fflag[b] == 3)) return;  // 3: k_pts's frame
     const int j = wd * 64 + lane;
@@ -147,21 +147,26 @@ struct SkyArgs {  // k_sky's blocks ride behind k_colT's (l1_cv with row flags):
     int nstrips, nblocks;  // blocks = strips x row groups; 0: none
 };
 __device__ __forceinline__ void sky_body(unsigned char *s_sky, const int *__restrict__ finfo, int H, int W, const float *dt_src, float *out_dt,
-                                         float *out_depth, int32_t *out_index, int strip, int rowgroup);
+                                         float *out_depth, int32_t *out_index, int strip, int rowgroup, int b);
 
 __global__ __launch_bounds__(1024) void k_colT(const u64 *__restrict__ srcbits, const int *__restrict__ fflag, int H,
                                                int W, int Wd, int nb, int CTP, uint2 *__restrict__ ct,
                                                const u16 *__restrict__ wpre_s, const u32 *__restrict__ rowbase_s,
-                                               uint4 *__restrict__ rec, int ncolblocks, const SkyArgs sky) {
+                                               uint4 *__restrict__ rec, int ncolblocks, const SkyArgs sky, int frames_x) {
     extern __shared__ __attribute__((aligned(16))) u16 s_lf[];
     __shared__ u64 s_rowword[16][64];
-    if ((int)blockIdx.x >= ncolblocks) {  // (block-uniform)
-        const int k = (int)blockIdx.x - ncolblocks;
+    // frames_x: frames along grid x, a frame's blocks along y -- with a batch of a multiple of eight frames a frame's blocks then run
+    // on one XCD: the sky's blocks read the two rows the window kernel left there, the column blocks the bit words (frames of up
+    // to 512 rows: 17.9 against 21.5 us on the scan-line batch; the 1024-thread blocks of a 2048-row frame want all XCDs: 32 against
+    // 60 us the other way round)
+    const int b = frames_x ? blockIdx.x : blockIdx.y, blk = frames_x ? blockIdx.y : blockIdx.x;
+    if (blk >= ncolblocks) {  // (block-uniform)
+        const int k = blk - ncolblocks;
         sky_body(reinterpret_cast<unsigned char *>(s_lf), sky.finfo, H, W, sky.dt_src, sky.out_dt, sky.out_depth, sky.out_index, k % sky.nstrips,
-                 k / sky.nstrips);
+                 k / sky.nstrips, b);
         return;
     }
-    colT_block(srcbits, fflag, H, W, Wd, nb, CTP, ct, wpre_s, rowbase_s, rec, (int)blockIdx.x, s_lf, s_rowword);
+    colT_block(srcbits, fflag, H, W, Wd, nb, CTP, ct, wpre_s, rowbase_s, rec, blk, b, s_lf, s_rowword);
 }
 
 __device__ __forceinline__ u32 ffbh_u32(u32 v) {  // position of the highest set bit from the top; 0xFFFFFFFF for 0

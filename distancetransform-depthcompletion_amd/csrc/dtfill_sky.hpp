@@ -32,8 +32,8 @@ __host__ __device__ inline int sky_span_max(int H, int W) { return min(W, SKY_SW
 __host__ __device__ inline size_t sky_lds(int span) { return (size_t)((span + 7) & ~7) * (2 * sizeof(u16) + 3 * sizeof(uint2)); }
 
 __device__ __forceinline__ void sky_body(unsigned char *s_sky, const int *__restrict__ finfo, int H, int W, const float *dt_src, float *out_dt,
-                                         float *out_depth, int32_t *out_index, int strip, int rowgroup) {
-    const int b = blockIdx.y, tid = threadIdx.x, NT = blockDim.x;  // (at least SKY_NT threads: the host sees to it)
+                                         float *out_depth, int32_t *out_index, int strip, int rowgroup, int b) {
+    const int tid = threadIdx.x, NT = blockDim.x;  // (at least SKY_NT threads: the host sees to it)
     const int r0 = finfo[b * FI_STRIDE + FI_SKY];
     const int i0 = rowgroup * SKY_RG;
     if (r0 <= 0 || r0 >= H || i0 >= r0) return;  // block-uniform: no sky in this frame (or called off), or not this far down
@@ -100,5 +100,5 @@ __device__ __forceinline__ void sky_body(unsigned char *s_sky, const int *__rest
 __global__ __launch_bounds__(SKY_NT) void k_sky(const int *__restrict__ finfo, int H, int W, const float *dt_src, float *out_dt, float *out_depth,
                                                 int32_t *out_index, int nstrips) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_skyraw[];
-    sky_body(s_skyraw, finfo, H, W, dt_src, out_dt, out_depth, out_index, (int)blockIdx.x % nstrips, (int)blockIdx.x / nstrips);
+    sky_body(s_skyraw, finfo, H, W, dt_src, out_dt, out_depth, out_index, (int)blockIdx.x % nstrips, (int)blockIdx.x / nstrips, (int)blockIdx.y);
 }
