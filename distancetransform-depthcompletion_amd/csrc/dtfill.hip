@@ -379,14 +379,14 @@ int run_l2(const float *x, int B, int H, int W, float src_thr, float val_thr, fl
         const int ntile = ((H + PT_T - 1) / PT_T) * ((W + PT_T - 1) / PT_T);
         if (4 * wave_lds <= 64 * 1024) {
             const int nrowblk = (H + 3) / 4;
-            k_l2env<4><<<dim3(nrowblk + (ntile + 3) / 4, B), 256, 4 * wave_lds, st>>>(x, c.ct, c.ctp, c.nb, c.rec, Wd, c.finfo, c.vlist, c.route,
+            k_l2env<4><<<dim3(B, nrowblk + (ntile + 3) / 4), 256, 4 * wave_lds, st>>>(x, c.ct, c.ctp, c.nb, c.rec, Wd, c.finfo, c.vlist, c.route,
                                                                                   c.rowfar, c.xlist, H, W, nrowblk, wave_lds, 1, out_depth,
                                                                                   out_dt, out_index, status);
         } else {
             if (wave_lds > 48 * 1024)  // rows wider than ~4900 pixels (set per call: the attribute belongs to the current device)
                 ok = ok && hipFuncSetAttribute(reinterpret_cast<const void *>(k_l2env<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)l2env_lds(8192)) == hipSuccess;
-            k_l2env<1><<<dim3(H + (ntile + 7) / 8, B), 64, wave_lds, st>>>(x, c.ct, c.ctp, c.nb, c.rec, Wd, c.finfo, c.vlist, c.route, c.rowfar, c.xlist,
+            k_l2env<1><<<dim3(B, H + (ntile + 7) / 8), 64, wave_lds, st>>>(x, c.ct, c.ctp, c.nb, c.rec, Wd, c.finfo, c.vlist, c.route, c.rowfar, c.xlist,
                                                                H, W, H, wave_lds, 8, out_depth, out_dt, out_index, status);
         }
     }

@@ -796,12 +796,14 @@ __global__ __launch_bounds__(64 * WPB, 5) void k_l2env(const float *__restrict__
                                                     float *__restrict__ out_dt, int32_t *__restrict__ out_index,
                                                     int *__restrict__ frame_status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_env[];
-    const int b = blockIdx.y, wv = threadIdx.x >> 6, r = route[b];
+    // (frames along grid x: a frame's blocks on one XCD -- where k_colT's blocks of that frame left the column words -- when the
+    // batch is a multiple of eight frames)
+    const int b = blockIdx.x, blk = blockIdx.y, wv = threadIdx.x >> 6, r = route[b];
     unsigned char *lds = s_env + (size_t)wv * wave_lds;
-    if ((int)blockIdx.x >= nrowblk) {
+    if (blk >= nrowblk) {
         if (r == ROUTE_POINTS) {
             const int tiles_x = (W + PT_T - 1) / PT_T, ntile = tiles_x * ((H + PT_T - 1) / PT_T);
-            const int t0 = (((int)blockIdx.x - nrowblk) * WPB + wv) * tpw;  // tpw tiles per wave (wide frames: fewer blocks)
+            const int t0 = ((blk - nrowblk) * WPB + wv) * tpw;  // tpw tiles per wave (wide frames: fewer blocks)
             for (int t = t0; t < min(ntile, t0 + tpw); ++t) {
                 l2pts_tile(x, srclist, finfo, vlist, b, H, W, t / tiles_x, t % tiles_x, out_depth, out_dt, out_index, frame_status, lds);
                 __builtin_amdgcn_wave_barrier();  // the next tile reuses the candidate list
@@ -809,7 +811,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void k_l2env(const float *__restrict__
         }
         return;
     }
-    const int i = (int)blockIdx.x * WPB + wv;
+    const int i = blk * WPB + wv;
     if (i >= H) return;
     if (r == 0)  // a sparse frame: few columns hold a source, the distances are large -- the envelope search
         l2env_row<1>(x, ct, CTP, nb, rec, Wd, finfo, vlist, H, W, b, i, out_depth, out_dt, out_index, frame_status, lds, nullptr);
